@@ -1,0 +1,644 @@
+// siren_fit.hip — C ABI (include/siren_fit.h) and host-side orchestration of the gfx950 kernels.
+//
+// One sf_engine == one per-image fit on one HIP stream.  A training step is, per pixel chunk:
+//   k_fwd -> k_bwdx -> k_dw(last) -> k_dw(hidden l = depth-2 .. 1) -> k_dw(first), each k_dw followed by
+//   k_reduce into the flat fp32 gradient; then k_adam (+mask) and k_images (16-bit weight images).
+// The sequence mirrors one `train_epoch` of the reference (implicit_image/utils/train_helper.py:132-185)
+// for the full-batch grid (implicit_image/compress.py:137-138).
+#include "siren_kernels.hip"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/siren_fit.h"
+
+using namespace sf;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(SF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+enum KernelId { K_FWD = 0, K_BWDX, K_DW_HIDDEN, K_DW_LAST, K_DW_FIRST, K_REDUCE, K_SSE, K_ADAM, K_IMAGES, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"k_fwd",    "k_bwdx", "k_dw_hidden", "k_dw_last", "k_dw_first",
+                                            "k_reduce", "k_sse",  "k_adam",      "k_images"};
+
+struct ProfRec {
+  int id;
+  hipEvent_t e0, e1;
+};
+
+struct sf_engine {
+  sf_config cfg;
+  int D = 0, WD = 0;
+  int64_t P = 0;
+  int64_t off_w[16], off_b[16];
+  hipStream_t stream = nullptr;
+  long npix = 0;          // local pixels
+  double n_total = 0;     // H*W of the full image
+  // state
+  float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *mask = nullptr;
+  bool has_mask = false;
+  int64_t step = 0;
+  // images
+  uint16_t *wf = nullptr, *wf_last = nullptr, *wb = nullptr, *wb_last = nullptr;
+  f32x4* l0tab = nullptr;
+  float *bias_h = nullptr, *bias_last = nullptr;
+  bool images_dirty = true;
+  float wscale = 1.f;
+  // data
+  float *gh = nullptr, *gw = nullptr;
+  bool have_coords = false;
+  const float* img = nullptr;
+  // scratch
+  long chunk_px = 0;
+  long p_stride = 0;  // pieces per layer
+  u32x4 *Pbuf = nullptr, *Dbuf = nullptr, *Dlast = nullptr;
+  float* slab = nullptr;
+  int dw_wg = 0;
+  float* sse_part = nullptr;
+  long n_sse = 0;
+  double* sse_dev = nullptr;
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  double prof_ms[K_COUNT] = {0};
+  int64_t prof_n[K_COUNT] = {0};
+  double prof_flops[K_COUNT] = {0}, prof_bytes[K_COUNT] = {0};
+};
+
+namespace {
+
+struct Launch {  // RAII-less helper: brackets a kernel launch with events when profiling
+  sf_engine* h;
+  int id;
+  ProfRec r;
+  Launch(sf_engine* h_, int id_, double flops, double bytes) : h(h_), id(id_) {
+    if (h->prof) {
+      r.id = id;
+      hipEventCreate(&r.e0);
+      hipEventCreate(&r.e1);
+      hipEventRecord(r.e0, h->stream);
+      h->prof_flops[id] = flops;
+      h->prof_bytes[id] = bytes;
+    }
+  }
+  void done() {
+    if (h->prof) {
+      hipEventRecord(r.e1, h->stream);
+      h->recs.push_back(r);
+    }
+  }
+};
+
+int prof_flush(sf_engine* h) {
+  if (h->recs.empty()) return SF_OK;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (auto& r : h->recs) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.e0, r.e1);
+    h->prof_ms[r.id] += ms;
+    h->prof_n[r.id] += 1;
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  h->recs.clear();
+  return SF_OK;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes));
+  return SF_OK;
+}
+
+size_t fwd_lds_bytes(int WD) { return (size_t)WD * WD * 2 + (size_t)WD * 16 + (size_t)(WD < 32 ? 32 : WD) * 4 + 64; }
+size_t bwd_lds_bytes(int WD) { return (size_t)WD * WD * 2 + 64; }
+
+template <int WD>
+int launch_fwd_t(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
+  const size_t lds = fwd_lds_bytes(WD);
+  const bool f16 = h->cfg.compute_dtype == SF_F16;
+#define SF_FWD(OP, TR)                                                   \
+  do {                                                                   \
+    int rc = set_lds(k_fwd<WD, OP, TR>, lds);                            \
+    if (rc) return rc;                                                   \
+    hipLaunchKernelGGL((k_fwd<WD, OP, TR>), dim3(n_super), dim3(512), lds, h->stream, a); \
+  } while (0)
+  if (f16) {
+    if (train) SF_FWD(OpF16, true); else SF_FWD(OpF16, false);
+  } else {
+    if (train) SF_FWD(OpBF16, true); else SF_FWD(OpBF16, false);
+  }
+#undef SF_FWD
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+
+template <int WD>
+int launch_bwdx_t(sf_engine* h, const BwdArgs& a, int n_super) {
+  const size_t lds = bwd_lds_bytes(WD);
+  int rc = set_lds(k_bwdx<WD>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_bwdx<WD>), dim3(n_super), dim3(512), lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+
+template <int ROWS, int COLS, int WR, int WC, int BSRC>
+int launch_dw_t(sf_engine* h, const DwArgs& a, int n_wg) {
+  const size_t lds = (size_t)2 * (ROWS / 16 + COLS / 16) * 1024;
+  int rc = set_lds(k_dw<ROWS, COLS, WR, WC, BSRC>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_dw<ROWS, COLS, WR, WC, BSRC>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+
+// which: 0 hidden, 1 last, 2 first
+int launch_dw(sf_engine* h, int which, const DwArgs& a, int n_wg) {
+  switch (h->WD) {
+    case 32:
+      if (which == 0) return launch_dw_t<32, 32, 1, 1, 0>(h, a, n_wg);
+      if (which == 1) return launch_dw_t<32, 32, 1, 1, 0>(h, a, n_wg);
+      return launch_dw_t<32, 32, 1, 1, 1>(h, a, n_wg);
+    case 64:
+      if (which == 0) return launch_dw_t<64, 64, 2, 2, 0>(h, a, n_wg);
+      if (which == 1) return launch_dw_t<32, 64, 1, 2, 0>(h, a, n_wg);
+      return launch_dw_t<64, 32, 2, 1, 1>(h, a, n_wg);
+    case 128:
+      if (which == 0) return launch_dw_t<128, 128, 2, 4, 0>(h, a, n_wg);
+      if (which == 1) return launch_dw_t<32, 128, 1, 4, 0>(h, a, n_wg);
+      return launch_dw_t<128, 32, 4, 1, 1>(h, a, n_wg);
+    case 256:
+      if (which == 0) return launch_dw_t<256, 256, 2, 4, 0>(h, a, n_wg);
+      if (which == 1) return launch_dw_t<32, 256, 1, 8, 0>(h, a, n_wg);
+      return launch_dw_t<256, 32, 8, 1, 1>(h, a, n_wg);
+  }
+  return fail(SF_ERR_INVALID, "unsupported hidden width");
+}
+
+int launch_fwd(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
+  switch (h->WD) {
+    case 32: return launch_fwd_t<32>(h, a, n_super, train);
+    case 64: return launch_fwd_t<64>(h, a, n_super, train);
+    case 128: return launch_fwd_t<128>(h, a, n_super, train);
+    case 256: return launch_fwd_t<256>(h, a, n_super, train);
+  }
+  return fail(SF_ERR_INVALID, "unsupported hidden width");
+}
+int launch_bwdx(sf_engine* h, const BwdArgs& a, int n_super) {
+  switch (h->WD) {
+    case 32: return launch_bwdx_t<32>(h, a, n_super);
+    case 64: return launch_bwdx_t<64>(h, a, n_super);
+    case 128: return launch_bwdx_t<128>(h, a, n_super);
+    case 256: return launch_bwdx_t<256>(h, a, n_super);
+  }
+  return fail(SF_ERR_INVALID, "unsupported hidden width");
+}
+
+int refresh_images(sf_engine* h) {
+  if (!h->images_dirty) return SF_OK;
+  ImgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = h->params;
+  a.depth = h->D;
+  a.WD = h->WD;
+  a.out_features = h->cfg.out_features;
+  for (int l = 0; l < h->D; ++l) {
+    a.off_w[l] = h->off_w[l];
+    a.off_b[l] = h->off_b[l];
+  }
+  a.wscale = h->wscale;
+  a.fwd_is_f16 = h->cfg.compute_dtype == SF_F16;
+  a.wf = h->wf; a.wf_last = h->wf_last; a.wb = h->wb; a.wb_last = h->wb_last;
+  a.l0tab = h->l0tab; a.bias_h = h->bias_h; a.bias_last = h->bias_last;
+  long n = (long)(h->D - 2) * h->WD * h->WD;
+  const long n_min = (long)h->WD / 16 * 64 * 8;  // also covers the small tables
+  if (n < n_min) n = n_min;
+  if (n < 1024) n = 1024;
+  Launch L(h, K_IMAGES, 0, (double)n * 8);
+  hipLaunchKernelGGL(k_images, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+  L.done();
+  HIPCHK(hipGetLastError());
+  h->images_dirty = false;
+  return SF_OK;
+}
+
+// algorithmic GEMM FLOPs per pixel: forward 2*P_w, backward 4*P_w - 4*WD
+double flops_fwd_px(const sf_engine* h) {
+  const double W = h->WD;
+  return 2.0 * (2 * W + (h->D - 2) * W * W + h->cfg.out_features * W);
+}
+double flops_bwdx_px(const sf_engine* h) {
+  const double W = h->WD;
+  return 2.0 * ((h->D - 2) * W * W + h->cfg.out_features * W);
+}
+
+int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
+  if (!h->have_coords) return fail(SF_ERR_STATE, "sf_set_coords has not been called");
+  if ((train || want_sse) && !h->img) return fail(SF_ERR_STATE, "sf_set_target has not been called");
+  int rc = refresh_images(h);
+  if (rc) return rc;
+  const int WD = h->WD, D = h->D, KS = WD / 16;
+  const long n_chunks = (h->npix + h->chunk_px - 1) / h->chunk_px;
+  long sse_off = 0;
+  for (long c = 0; c < n_chunks; ++c) {
+    const long pix0 = c * h->chunk_px;
+    long px = h->npix - pix0;
+    if (px > h->chunk_px) px = h->chunk_px;
+    const int n_super = (int)((px + kSuper - 1) / kSuper);
+    const long n_pb = (long)n_super * kWavesFwd;
+    FwdArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.gh = h->gh; fa.gw = h->gw; fa.W = h->cfg.width; fa.row_begin = h->cfg.row_begin;
+    fa.pix0 = pix0; fa.npix = h->npix; fa.depth = D;
+    fa.l0tab = h->l0tab;
+    fa.wf = reinterpret_cast<const u32x4*>(h->wf);
+    fa.wf_last = reinterpret_cast<const u32x4*>(h->wf_last);
+    fa.bias_h = h->bias_h; fa.bias_last = h->bias_last;
+    const double two_pi = 6.283185307179586476925286766559;
+    fa.sc_first = (float)((double)h->cfg.first_omega_0 / two_pi);
+    fa.sc_hidden = (float)((double)h->cfg.hidden_omega_0 / two_pi / (double)h->wscale);
+    fa.sc_last = 1.0f / h->wscale;
+    fa.P = h->Pbuf; fa.p_stride = h->p_stride; fa.Dlast = h->Dlast;
+    fa.img = h->img;
+    fa.gscale = (float)(1.0 / (3.0 * h->n_total));
+    fa.pred = pred;
+    fa.sse_part = h->sse_part + sse_off;
+    sse_off += n_super;
+    {
+      Launch L(h, K_FWD, flops_fwd_px(h) * n_pb * 32.0,
+               n_pb * 32.0 * (12.0 + (train ? (D - 1) * WD * 2.0 + 64.0 : 0.0)));
+      rc = launch_fwd(h, fa, n_super, train);
+      L.done();
+      if (rc) return rc;
+    }
+    if (!train) continue;
+    BwdArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    ba.depth = D;
+    ba.wb = reinterpret_cast<const u32x4*>(h->wb);
+    ba.wb_last = reinterpret_cast<const u32x4*>(h->wb_last);
+    ba.P = h->Pbuf; ba.p_stride = h->p_stride; ba.Dlast = h->Dlast; ba.D = h->Dbuf;
+    ba.om_first = h->cfg.first_omega_0; ba.om_hidden = h->cfg.hidden_omega_0;
+    {
+      Launch L(h, K_BWDX, flops_bwdx_px(h) * n_pb * 32.0, n_pb * 32.0 * ((D - 1) * WD * 4.0 + 64.0));
+      rc = launch_bwdx(h, ba, n_super);
+      L.done();
+      if (rc) return rc;
+    }
+    // weight gradients, last layer first (autograd order is irrelevant: each layer has its own slab pass)
+    const int PBS = 2;
+    int n_wg = (int)((n_pb + PBS - 1) / PBS);
+    if (n_wg > h->dw_wg) n_wg = h->dw_wg;
+    long pb_per_wg = (n_pb + n_wg - 1) / n_wg;
+    pb_per_wg = (pb_per_wg + PBS - 1) / PBS * PBS;
+    n_wg = (int)((n_pb + pb_per_wg - 1) / pb_per_wg);
+    for (int l = D - 1; l >= 0; --l) {
+      DwArgs da;
+      memset(&da, 0, sizeof(da));
+      da.gh = h->gh; da.gw = h->gw; da.W = h->cfg.width; da.row_begin = h->cfg.row_begin;
+      da.pix0 = pix0; da.npix = h->npix; da.n_pb = n_pb; da.pb_per_wg = (int)pb_per_wg; da.slab = h->slab;
+      ReduceArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.slab = h->slab; ra.n_wg = n_wg; ra.accumulate = c > 0;
+      ra.gW = h->grads + h->off_w[l]; ra.gb = h->grads + h->off_b[l];
+      int which, kid;
+      double fl, by;
+      if (l == D - 1) {
+        which = 1; kid = K_DW_LAST;
+        da.A = h->Dlast;
+        da.Bp = h->Pbuf + (size_t)(D - 2) * h->p_stride;
+        ra.slab_rows = 32; ra.slab_cols = WD; ra.rows_out = h->cfg.out_features; ra.cols_out = WD; ra.mode = 0;
+        fl = 2.0 * h->cfg.out_features * WD; by = 64.0 + WD * 2.0;
+      } else if (l == 0) {
+        which = 2; kid = K_DW_FIRST;
+        da.A = h->Dbuf;
+        ra.slab_rows = WD; ra.slab_cols = 32; ra.rows_out = WD; ra.cols_out = 2; ra.mode = 1;
+        fl = 2.0 * 2 * WD; by = WD * 2.0;
+      } else {
+        which = 0; kid = K_DW_HIDDEN;
+        da.A = h->Dbuf + (size_t)l * h->p_stride;
+        da.Bp = h->Pbuf + (size_t)(l - 1) * h->p_stride;
+        ra.slab_rows = WD; ra.slab_cols = WD; ra.rows_out = WD; ra.cols_out = WD; ra.mode = 0;
+        fl = 2.0 * WD * WD; by = WD * 4.0;
+      }
+      {
+        Launch L(h, kid, fl * n_pb * 32.0, by * n_pb * 32.0);
+        rc = launch_dw(h, which, da, n_wg);
+        L.done();
+        if (rc) return rc;
+      }
+      {
+        const int n = ra.rows_out * ra.cols_out + ra.rows_out;
+        Launch L(h, K_REDUCE, 0, (double)n_wg * n * 4.0);
+        hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, h->stream, ra);
+        L.done();
+        HIPCHK(hipGetLastError());
+      }
+    }
+    (void)KS;
+  }
+  if (want_sse || train) {
+    Launch L(h, K_SSE, 0, (double)sse_off * 4);
+    hipLaunchKernelGGL(k_sse_reduce, dim3(1), dim3(256), 0, h->stream, (const float*)h->sse_part, (int)sse_off,
+                       h->sse_dev);
+    L.done();
+    HIPCHK(hipGetLastError());
+  }
+  return SF_OK;
+}
+
+int read_sse(sf_engine* h, double* out) {
+  HIPCHK(hipMemcpyAsync(out, h->sse_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return SF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sf_abi_version(void) { return SF_ABI_VERSION; }
+const char* sf_last_error(void) { return g_err.c_str(); }
+
+int sf_create(const sf_config* cfg, sf_handle** out) {
+  if (!cfg || !out) return fail(SF_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != SF_ABI_VERSION) return fail(SF_ERR_INVALID, "abi_version mismatch");
+  if (cfg->in_features != 2) return fail(SF_ERR_INVALID, "in_features must be 2 (coordinate grid)");
+  if (cfg->out_features < 1 || cfg->out_features > 3) return fail(SF_ERR_INVALID, "out_features must be 1..3");
+  if (cfg->depth < 2 || cfg->depth > 16) return fail(SF_ERR_INVALID, "depth must be 2..16");
+  if (cfg->hidden != 32 && cfg->hidden != 64 && cfg->hidden != 128 && cfg->hidden != 256)
+    return fail(SF_ERR_INVALID, "hidden must be 32, 64, 128 or 256 in this build");
+  if (!cfg->outermost_linear) return fail(SF_ERR_INVALID, "outermost_linear=False is not supported");
+  if (cfg->compute_dtype != SF_BF16 && cfg->compute_dtype != SF_F16)
+    return fail(SF_ERR_INVALID, "compute_dtype must be SF_BF16 or SF_F16");
+  if (cfg->height < 1 || cfg->width < 1) return fail(SF_ERR_INVALID, "bad image size");
+  int r0 = cfg->row_begin, r1 = cfg->row_end;
+  if (r0 == 0 && r1 == 0) r1 = cfg->height;
+  if (r0 < 0 || r1 > cfg->height || r0 >= r1) return fail(SF_ERR_INVALID, "bad row range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SF_ERR_NO_DEVICE, "no HIP device visible");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(SF_ERR_INVALID, "bad device ordinal");
+  HIPCHK(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SF_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950");
+
+  sf_engine* h = new sf_engine();
+  h->cfg = *cfg;
+  h->cfg.row_begin = r0;
+  h->cfg.row_end = r1;
+  if (h->cfg.beta1 == 0.f && h->cfg.beta2 == 0.f && h->cfg.eps == 0.f) {
+    h->cfg.beta1 = 0.9f; h->cfg.beta2 = 0.999f; h->cfg.eps = 1e-8f;
+  }
+  h->D = cfg->depth;
+  h->WD = cfg->hidden;
+  h->stream = (hipStream_t)cfg->stream;
+  h->npix = (long)(r1 - r0) * cfg->width;
+  h->n_total = (double)cfg->height * (double)cfg->width;
+  // flat parameter offsets: named_parameters() order (siren.py:90-118)
+  int64_t off = 0;
+  for (int l = 0; l < h->D; ++l) {
+    const int in = l == 0 ? 2 : h->WD, outn = l == h->D - 1 ? cfg->out_features : h->WD;
+    h->off_w[l] = off; off += (int64_t)in * outn;
+    h->off_b[l] = off; off += outn;
+  }
+  h->P = off;
+  // fp16 forward images are scaled by 2^8 so that small weights stay normal numbers
+  h->wscale = cfg->compute_dtype == SF_F16 ? 256.0f : 1.0f;
+  // chunking
+  long chunk = cfg->chunk_pixels > 0 ? cfg->chunk_pixels : (1L << 20);
+  chunk = (chunk + kSuper - 1) / kSuper * kSuper;
+  const long npix_pad = (h->npix + kSuper - 1) / kSuper * kSuper;
+  if (chunk > npix_pad) chunk = npix_pad;
+  h->chunk_px = chunk;
+  const int WD = h->WD, D = h->D;
+  h->p_stride = chunk / 32 * (WD / 16) * 64;
+  h->dw_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+  auto alloc = [&](void** p, size_t bytes) -> int {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(SF_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    return SF_OK;
+  };
+  int rc = SF_OK;
+#define ALLOC(ptr, bytes) if (!rc) rc = alloc((void**)&(ptr), (bytes))
+  ALLOC(h->params, h->P * 4); ALLOC(h->grads, h->P * 4); ALLOC(h->m, h->P * 4); ALLOC(h->v, h->P * 4);
+  ALLOC(h->mask, h->P * 4);
+  const size_t img_elems = (size_t)(D - 2 > 0 ? D - 2 : 1) * WD * WD;
+  ALLOC(h->wf, img_elems * 2); ALLOC(h->wb, img_elems * 2);
+  ALLOC(h->wf_last, (size_t)WD / 16 * 64 * 16); ALLOC(h->wb_last, (size_t)WD / 32 * 64 * 16);
+  ALLOC(h->l0tab, (size_t)WD * 16); ALLOC(h->bias_h, img_elems / WD * 4); ALLOC(h->bias_last, 32 * 4);
+  ALLOC(h->gh, (size_t)cfg->height * 4); ALLOC(h->gw, (size_t)cfg->width * 4);
+  ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->p_stride * 16);
+  ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
+  ALLOC(h->slab, (size_t)h->dw_wg * ((size_t)WD * WD + WD) * 4);
+  h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
+  ALLOC(h->sse_part, h->n_sse * 4); ALLOC(h->sse_dev, 8);
+#undef ALLOC
+  if (rc) { sf_destroy(h); return rc; }
+  hipMemsetAsync(h->params, 0, h->P * 4, h->stream);
+  hipMemsetAsync(h->grads, 0, h->P * 4, h->stream);
+  hipMemsetAsync(h->m, 0, h->P * 4, h->stream);
+  hipMemsetAsync(h->v, 0, h->P * 4, h->stream);
+  *out = h;
+  return SF_OK;
+}
+
+int sf_destroy(sf_handle* h) {
+  if (!h) return SF_OK;
+  if (h->stream || true) hipStreamSynchronize(h->stream);
+  for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab,
+                  h->bias_h, h->bias_last, h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part,
+                  h->sse_dev};
+  for (void* p : ptrs) if (p) hipFree(p);
+  delete h;
+  return SF_OK;
+}
+
+int sf_num_params(const sf_handle* h, int64_t* n) {
+  if (!h || !n) return fail(SF_ERR_INVALID, "null argument");
+  *n = h->P;
+  return SF_OK;
+}
+int sf_param_offset(const sf_handle* h, int32_t layer, int64_t* w, int64_t* b) {
+  if (!h || layer < 0 || layer >= h->D) return fail(SF_ERR_INVALID, "bad layer");
+  if (w) *w = h->off_w[layer];
+  if (b) *b = h->off_b[layer];
+  return SF_OK;
+}
+
+static int copy_in(sf_engine* h, float* dst, const float* src) {
+  if (!h || !src) return fail(SF_ERR_INVALID, "null argument");
+  HIPCHK(hipMemcpyAsync(dst, src, h->P * 4, hipMemcpyDeviceToDevice, h->stream));
+  return SF_OK;
+}
+static int copy_out(sf_engine* h, float* dst, const float* src) {
+  if (!h || !dst) return fail(SF_ERR_INVALID, "null argument");
+  HIPCHK(hipMemcpyAsync(dst, src, h->P * 4, hipMemcpyDeviceToDevice, h->stream));
+  return SF_OK;
+}
+int sf_set_params(sf_handle* h, const float* p) {
+  int rc = copy_in(h, h ? h->params : nullptr, p);
+  if (!rc) h->images_dirty = true;
+  return rc;
+}
+int sf_get_params(sf_handle* h, float* p) { return copy_out(h, p, h ? h->params : nullptr); }
+int sf_get_grads(sf_handle* h, float* p) { return copy_out(h, p, h ? h->grads : nullptr); }
+int sf_set_grads(sf_handle* h, const float* p) { return copy_in(h, h ? h->grads : nullptr, p); }
+int sf_set_masks(sf_handle* h, const float* p) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  if (!p) { h->has_mask = false; return SF_OK; }
+  int rc = copy_in(h, h->mask, p);
+  if (!rc) h->has_mask = true;
+  return rc;
+}
+int sf_get_adam_state(sf_handle* h, float* m, float* v, int64_t* step) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  if (m) { int rc = copy_out(h, m, h->m); if (rc) return rc; }
+  if (v) { int rc = copy_out(h, v, h->v); if (rc) return rc; }
+  if (step) *step = h->step;
+  return SF_OK;
+}
+int sf_set_adam_state(sf_handle* h, const float* m, const float* v, int64_t step) {
+  if (!h || step < 0) return fail(SF_ERR_INVALID, "bad argument");
+  if (m) { int rc = copy_in(h, h->m, m); if (rc) return rc; }
+  if (v) { int rc = copy_in(h, h->v, v); if (rc) return rc; }
+  h->step = step;
+  return SF_OK;
+}
+int sf_state_ptr(sf_handle* h, int32_t which, float** p) {
+  if (!h || !p) return fail(SF_ERR_INVALID, "null argument");
+  switch (which) {
+    case 0: *p = h->params; return SF_OK;
+    case 1: *p = h->grads; return SF_OK;
+    case 2: *p = h->m; return SF_OK;
+    case 3: *p = h->v; return SF_OK;
+    case 4: *p = h->mask; return SF_OK;
+  }
+  return fail(SF_ERR_INVALID, "bad state selector");
+}
+
+int sf_params_changed(sf_handle* h) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  h->images_dirty = true;
+  return SF_OK;
+}
+
+int sf_set_coords(sf_handle* h, const float* rows, const float* cols) {
+  if (!h || !rows || !cols) return fail(SF_ERR_INVALID, "null argument");
+  HIPCHK(hipMemcpyAsync(h->gh, rows, (size_t)h->cfg.height * 4, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->gw, cols, (size_t)h->cfg.width * 4, hipMemcpyDeviceToDevice, h->stream));
+  h->have_coords = true;
+  return SF_OK;
+}
+int sf_set_target(sf_handle* h, const float* img) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  h->img = img;
+  return SF_OK;
+}
+
+int sf_forward(sf_handle* h, float* pred, double* sse_out) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  const bool want = sse_out != nullptr;
+  const float* keep = h->img;
+  int rc = run_pass(h, false, pred, want);
+  h->img = keep;
+  if (rc) return rc;
+  if (want) return read_sse(h, sse_out);
+  return SF_OK;
+}
+
+int sf_forward_backward(sf_handle* h, double* sse_out) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  int rc = run_pass(h, true, nullptr, true);
+  if (rc) return rc;
+  if (sse_out) return read_sse(h, sse_out);
+  return SF_OK;
+}
+
+int sf_adam_step(sf_handle* h, float lr) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  h->step += 1;
+  AdamArgs a;
+  a.p = h->params; a.g = h->grads; a.m = h->m; a.v = h->v; a.mask = h->has_mask ? h->mask : nullptr;
+  a.n = h->P;
+  a.beta1 = h->cfg.beta1; a.beta2 = h->cfg.beta2; a.eps = h->cfg.eps;
+  const double bc1 = 1.0 - pow((double)h->cfg.beta1, (double)h->step);
+  const double bc2 = 1.0 - pow((double)h->cfg.beta2, (double)h->step);
+  a.step_size = (float)((double)lr / bc1);
+  a.bc2_sqrt = (float)sqrt(bc2);
+  Launch L(h, K_ADAM, 0, (double)h->P * 28);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((h->P + 255) / 256)), dim3(256), 0, h->stream, a);
+  L.done();
+  HIPCHK(hipGetLastError());
+  h->images_dirty = true;
+  return refresh_images(h);
+}
+
+int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) {
+  if (!h || !lr || n_steps < 0) return fail(SF_ERR_INVALID, "bad argument");
+  for (int i = 0; i < n_steps; ++i) {
+    int rc = run_pass(h, true, nullptr, true);
+    if (rc) return rc;
+    if (loss_out) {
+      double sse = 0;
+      rc = read_sse(h, &sse);
+      if (rc) return rc;
+      loss_out[i] = (float)(sse / (3.0 * (double)h->npix));
+    }
+    rc = sf_adam_step(h, lr[i]);
+    if (rc) return rc;
+  }
+  return SF_OK;
+}
+
+int sf_profile_enable(sf_handle* h, int32_t on) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  if (!on) { int rc = prof_flush(h); if (rc) return rc; }
+  h->prof = on != 0;
+  return SF_OK;
+}
+int sf_profile_reset(sf_handle* h) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  int rc = prof_flush(h);
+  if (rc) return rc;
+  for (int i = 0; i < K_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+  return SF_OK;
+}
+int sf_profile_num_kernels(const sf_handle* h, int32_t* n) {
+  if (!h || !n) return fail(SF_ERR_INVALID, "null argument");
+  *n = K_COUNT;
+  return SF_OK;
+}
+int sf_profile_get(sf_handle* h, int32_t idx, const char** name, double* total_ms, int64_t* launches,
+                   double* flops_per_launch, double* bytes_per_launch) {
+  if (!h || idx < 0 || idx >= K_COUNT) return fail(SF_ERR_INVALID, "bad kernel index");
+  int rc = prof_flush(h);
+  if (rc) return rc;
+  if (name) *name = kKernelNames[idx];
+  if (total_ms) *total_ms = h->prof_ms[idx];
+  if (launches) *launches = h->prof_n[idx];
+  if (flops_per_launch) *flops_per_launch = h->prof_flops[idx];
+  if (bytes_per_launch) *bytes_per_launch = h->prof_bytes[idx];
+  return SF_OK;
+}
+
+}  // extern "C"
