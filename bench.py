@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixel-iters/s of one full SIREN fit step (forward + MSE + backward + Adam)
+at hidden 256 x depth 8 on a synthetic 4096x4096x3 grid (BASELINE.json `metric`).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; each rank fits its own image —
+   per-image sharding, no data-path collective, weak scaling.)
+
+Prints ONE JSON line on rank 0 with the contract keys plus
+  roofline      MFMA roofline of the dominant kernel (algorithmic GEMM FLOPs / HIP-event duration)
+  cpu_baseline  the CPU oracle (fp32 restatement of the reference step) timed on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "implicit-image-compression_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak of MI355X (MI355X_MICROARCH.md chip table)
+
+
+def flops_per_pixel_iter(hidden, depth, out_features=3):
+    """F = 6*P_w - 4*hidden, P_w = 2W + (D-2)W^2 + 3W (GEMM multiply-adds only)."""
+    pw = 2 * hidden + (depth - 2) * hidden * hidden + out_features * hidden
+    return 6 * pw - 4 * hidden
+
+
+def device_image(h, w, device, seed=1234):
+    """SURVEY.md §8(d) synthetic target generated on the device: sinusoids + seeded uniform noise."""
+    ys = torch.linspace(0, 1, h, device=device)[:, None, None]
+    xs = torch.linspace(0, 1, w, device=device)[None, :, None]
+    kx = torch.tensor([1.0, 2.0, 3.0], device=device)
+    ky = torch.tensor([3.0, 1.0, 2.0], device=device)
+    img = 0.5 + 0.25 * torch.sin(12 * xs * kx) + 0.25 * torch.cos(9 * ys * ky)
+    g = torch.Generator(device=device).manual_seed(seed)
+    img = img + 0.05 * (torch.rand(h, w, 3, device=device, generator=g) * 2 - 1)
+    return img.clamp_(0, 1).contiguous()
+
+
+def cpu_baseline(hidden, depth, size, warm=1, timed=3):
+    """The oracle's train step (fp32 restatement of train_helper.py:132-185) on the host cores.
+    Bounded sample: `size` x `size` grid (the 4096^2 grid needs ~325 GB of fp32 activations on this
+    path); Mpixel-iters/s is size-normalised."""
+    from oracle import siren_oracle as so
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    p = so.siren_init(hidden, depth, seed=0)
+    img = so.synthetic_image(size, size)
+    grid = so.get_grid(size, size)
+    opt = so.Adam(p)
+    for t in range(warm):
+        so.train_epoch(p, opt, grid, img, t)
+    t0 = time.perf_counter()
+    for t in range(timed):
+        so.train_epoch(p, opt, grid, img, warm + t)
+    dt = (time.perf_counter() - t0) / timed
+    return {"value": size * size / dt / 1e6, "unit": "Mpixel-iters/s", "cores": cores, "kind": "port",
+            "sample": f"{timed} full-batch steps of SIREN {hidden}x{depth} on a {size}x{size} grid, fp32 torch CPU "
+                      f"oracle, {dt * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--cpu-size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from implicit_image._engine import SirenEngine
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    H = W = args.size
+    eng = SirenEngine(H, W, args.hidden, args.depth, compute_dtype=args.dtype, device=local_rank,
+                      chunk_pixels=args.chunk)
+    # per-image sharding: every rank fits its own synthetic image (seed offset by rank), same init
+    from implicit_image.models import Siren   # seed-0 SIREN init, random-init weights
+    torch.manual_seed(0)
+    init = Siren(depth=args.depth, hidden_size=args.hidden, first_omega_0=50.0, hidden_omega_0=30.0)
+    eng.set_params(torch.cat([q.detach().reshape(-1) for q in init.parameters()]).to(dev))
+    eng.set_coords(torch.linspace(0, 1, H).to(dev), torch.linspace(0, 1, W).to(dev))
+    img = device_image(H, W, dev, seed=1234 + rank)
+    eng.set_target(img)
+    lr = 3e-4
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    eng.step([lr] * args.warmup)
+    barrier()
+    eng.profile(True)
+    eng.profile_reset()
+    t0 = time.perf_counter()
+    eng.step([lr] * args.steps)          # no host sync inside: losses stay on the device
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    rep = eng.profile_report()
+    eng.profile(False)
+    _, sse = eng.forward(want_pred=False)
+    psnr = 10 * torch.log10(torch.tensor(3.0 * H * W / sse)).item()
+
+    if rank == 0:
+        F = flops_per_pixel_iter(args.hidden, args.depth)
+        value = world * H * W * args.steps / dt / 1e6
+        kern = {k: v for k, v in rep.items() if v["launches"]}
+        dom = max((k for k in kern if kern[k]["flops_per_launch"] > 0), key=lambda k: kern[k]["total_ms"])
+        d = kern[dom]
+        avg_ms = d["total_ms"] / d["launches"]
+        ach = d["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mpixel-iters/s (fwd+bwd+Adam) @ SIREN-256x8",
+            "value": value, "unit": "Mpixel-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 fwd / bf16 bwd operands, f32 accumulate" if args.dtype == "f16" else "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"siren_{args.hidden}x{args.depth}_fit_step_{H}x{W}x3_grid", "image": f"{H}x{W}x3",
+                       "hidden": args.hidden, "depth": args.depth, "sharding": f"per-image x{world}",
+                       "chunk_pixels": eng.npix if args.chunk == 0 and eng.npix < (1 << 20) else (args.chunk or 1 << 20)},
+            "step_mfma_frac": value / world * 1e6 * F / (PEAK_BF16_TFLOPS * 1e12),
+            "psnr_after_run": psnr,
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "flops_per_launch": d["flops_per_launch"]},
+            "kernels": {k: {"ms_per_step": v["total_ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                            "tflops": (v["flops_per_launch"] * v["launches"] / (v["total_ms"] * 1e-3) / 1e12)
+                            if v["total_ms"] > 0 else 0.0,
+                            "algorithmic_GBps": (v["bytes_per_launch"] * v["launches"] / (v["total_ms"] * 1e-3) / 1e9)
+                            if v["total_ms"] > 0 else 0.0} for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.hidden, args.depth, args.cpu_size)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

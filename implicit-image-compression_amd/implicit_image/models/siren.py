@@ -1,0 +1,145 @@
+"""SIREN model with the reference's constructor, parameter names and call signature
+(reference: implicit_image/models/siren.py:9-134), executed by the gfx950 engine.
+
+The torch module only OWNS NAMES AND SHAPES: once bound, every `layers.{i}.linear.{weight,bias}`
+Parameter (and its .grad) is a zero-copy view of the engine's flat fp32 state, so optimiser /
+masking / quantisation code that pokes `weight.data`, `weight.grad` or iterates
+`named_parameters()` sees live engine state.  forward() runs the fused HIP kernels; there is no
+PyTorch arithmetic fallback.
+"""
+import copy
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..data import grid_vectors
+
+
+class SineLayer(nn.Module):
+    """Linear -> sin(omega_0 * z) (reference siren.py:9-68).  Holds the nn.Linear so that
+    `isinstance(m, nn.Linear)` scans (masking, k-means, entropy coding) find it under `.linear`."""
+
+    def __init__(self, in_features: int, out_features: int, has_bias: bool = True, is_first: bool = False,
+                 omega_0: float = 30.0, no_activation: bool = False):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.is_first, self.omega_0, self.no_activation = is_first, omega_0, no_activation
+        # nn.Linear's default init draws (weight, then bias) come first, as in the reference, so the
+        # generator state and the bias values match a reference model built from the same seed
+        self.linear = nn.Linear(in_features, out_features, bias=has_bias)
+        bound = 1 / in_features if is_first else np.sqrt(6 / in_features) / omega_0
+        with torch.no_grad():
+            self.linear.weight.uniform_(-bound, bound)
+        self.linear.scaler = bound
+
+    def forward(self, x):  # pragma: no cover - the layers never run individually
+        raise RuntimeError("SineLayer is executed by the fused engine; call Siren.forward(grid)")
+
+
+class Siren(nn.Module):
+    def __init__(self, input_size: int = 2, output_size: int = 3, depth: int = 8, hidden_size: int = 128,
+                 first_omega_0: float = 50.0, hidden_omega_0: float = 50.0, outermost_linear: bool = True,
+                 simulate_quantization: bool = False, small_dense_density: float = 1.0,
+                 compute_dtype: str = "f16", chunk_pixels: int = 0, **kwargs):
+        super().__init__()
+        if simulate_quantization:
+            raise NotImplementedError("simulate_quantization (QAT stubs) is outside the accelerated path")
+        hidden_size = int(hidden_size * np.sqrt(small_dense_density))   # Small_Dense (reference siren.py:88)
+        layers = [SineLayer(input_size, hidden_size, is_first=True, omega_0=first_omega_0)]
+        for _ in range(depth - 2):
+            layers.append(SineLayer(hidden_size, hidden_size, omega_0=hidden_omega_0))
+        layers.append(SineLayer(hidden_size, output_size, omega_0=hidden_omega_0, no_activation=outermost_linear))
+        self.layers = nn.Sequential(*layers)
+        self.simulate_quantization = simulate_quantization
+        self.cfg = dict(input_size=input_size, output_size=output_size, depth=depth, hidden_size=hidden_size,
+                        first_omega_0=float(first_omega_0), hidden_omega_0=float(hidden_omega_0),
+                        outermost_linear=bool(outermost_linear), compute_dtype=compute_dtype,
+                        chunk_pixels=chunk_pixels)
+        self._engine = None
+        self._engine_key = None
+        self._grid_key = None
+        self._target_key = None
+
+    # ---- engine binding -------------------------------------------------------------------
+    def _param_list(self):
+        return list(self.parameters())
+
+    def engine(self, grid: torch.Tensor, img: Optional[torch.Tensor] = None, row_begin: int = 0, row_end: int = 0,
+               full_height: Optional[int] = None):
+        """Engine bound to this model for `grid` (created on first use / when the image size changes)."""
+        from .._engine import SirenEngine
+        if not grid.is_cuda:
+            raise RuntimeError("Siren runs on the gfx950 engine only: move model, grid and image to 'cuda'")
+        h, w, _ = grid.shape
+        H = full_height or h
+        key = (H, w, row_begin, row_end, grid.device.index)
+        if self._engine is None or self._engine_key != key:
+            c = self.cfg
+            if self._engine is not None:
+                self._unbind()
+            self._engine = SirenEngine(H, w, c["hidden_size"], c["depth"], c["first_omega_0"], c["hidden_omega_0"],
+                                       c["outermost_linear"], c["output_size"], c["compute_dtype"],
+                                       device=grid.device.index or 0, row_begin=row_begin, row_end=row_end,
+                                       chunk_pixels=c["chunk_pixels"])
+            self._engine_key, self._grid_key, self._target_key = key, None, None
+        eng = self._engine
+        gkey = (grid.data_ptr(), tuple(grid.shape))
+        if self._grid_key != gkey:
+            rows, cols = grid_vectors(grid)
+            if full_height and full_height != h:
+                raise ValueError("pass the full-height grid in pixel-split mode")
+            eng.set_coords(rows.float(), cols.float())
+            self._grid_key = gkey
+        if img is not None:
+            tkey = (img.data_ptr(), tuple(img.shape), img._version)
+            if self._target_key != tkey:
+                eng.set_target(img.contiguous().float())
+                self._target_key = tkey
+        self._sync_to_engine()
+        return eng
+
+    def _sync_to_engine(self):
+        """(Re)bind every Parameter to its slice of the engine's flat buffers.  Code that REPLACED
+        `weight.data` (e.g. `weight.data = weight.data * mask`) is detected by pointer and copied in."""
+        eng = self._engine
+        flat, grads = eng.view("params"), eng.view("grads")
+        off = 0
+        for p in self._param_list():
+            n = p.numel()
+            dst = flat[off:off + n].view(p.shape)
+            if p.data.data_ptr() != dst.data_ptr():
+                dst.copy_(p.data.to(dst.dtype))
+                p.data = dst
+            g = grads[off:off + n].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+            off += n
+        eng.params_changed()   # in-place edits through the views are invisible to the engine: always refresh
+
+    def _unbind(self):
+        for p in self._param_list():
+            p.data = p.data.clone()
+            p.grad = None
+        self._engine.close()
+        self._engine = None
+
+    def __deepcopy__(self, memo):
+        c = self.cfg
+        new = Siren(c["input_size"], c["output_size"], c["depth"], c["hidden_size"], c["first_omega_0"],
+                    c["hidden_omega_0"], c["outermost_linear"], compute_dtype=c["compute_dtype"],
+                    chunk_pixels=c["chunk_pixels"])
+        new.to(next(self.parameters()).device)
+        with torch.no_grad():
+            for a, b in zip(new.parameters(), self.parameters()):
+                a.copy_(b)
+        new.train(self.training)
+        return new
+
+    # ---- reference call signature -----------------------------------------------------------
+    def forward(self, grid: torch.Tensor) -> torch.Tensor:
+        """[H, W, 2] grid -> [H, W, output_size] prediction in [0, 1] (reference siren.py:123-134)."""
+        pred, _ = self.engine(grid).forward(want_pred=True, want_sse=False)
+        return pred

@@ -1,0 +1,221 @@
+"""Masking: wraps a model's weights with 0/1 masks (reference: pipeline/masking/core.py).
+
+Differences from the reference are deliberate and documented:
+  * the per-step `apply_mask` (core.py:271-279) is executed INSIDE the engine's Adam kernel when the
+    model is engine-bound; the masks are pushed to the engine whenever the topology changes;
+  * the FLOP counter (pipeline/masking/counting/) is logging only and is not rebuilt, but the two
+    `torch.rand(*input_size)` draws it makes on the CPU generator (core.py:371,384) ARE reproduced,
+    because the ERK masks drawn between them depend on the generator position.
+Supported registry keys: sparse_init erdos-renyi(-kernel); prune_mode magnitude; growth_mode
+absolute-gradient | none; redistribution_mode none | nonzero; decay cosine.
+"""
+import logging
+from dataclasses import dataclass, field
+from typing import Dict
+
+import numpy as np
+import torch
+from torch import nn
+
+from .funcs import grow_registry, init_registry, prune_registry, redistribute_registry
+
+
+@dataclass
+class LayerStats:
+    variance_dict: Dict[str, float] = field(default_factory=dict)
+    zeros_dict: Dict[str, int] = field(default_factory=dict)
+    nonzeros_dict: Dict[str, int] = field(default_factory=dict)
+    removed_dict: Dict[str, int] = field(default_factory=dict)
+    total_variance: float = 0
+    total_zero: int = 0
+    total_nonzero: int = 0
+    total_removed: int = 0
+
+    @property
+    def total_density(self) -> float:
+        tot = self.total_zero + self.total_nonzero
+        return self.total_nonzero / tot if tot else 0.0
+
+
+class Masking:
+    def __init__(self, optimizer, prune_rate_decay, density: float = 0.2, sparse_init: str = "random",
+                 dense_gradients: bool = False, prune_mode: str = "magnitude", growth_mode: str = "momentum",
+                 redistribution_mode: str = "momentum", input_size=(1, 3, 32, 32)):
+        assert sparse_init in init_registry, f"Sparse init {sparse_init} not found. Available {init_registry.keys()}"
+        assert growth_mode in grow_registry or growth_mode == "none", \
+            f"Available growth modes: {','.join(grow_registry.keys())}"
+        assert prune_mode in prune_registry, f"Available prune modes: {','.join(prune_registry.keys())}"
+        assert redistribution_mode in redistribute_registry, \
+            f"Available redistribute modes: {','.join(redistribute_registry.keys())}"
+        self.optimizer, self.prune_rate_decay = optimizer, prune_rate_decay
+        self.density, self.sparse_init, self.dense_gradients = density, sparse_init, dense_gradients
+        self.prune_mode, self.growth_mode, self.redistribution_mode = prune_mode, growth_mode, redistribution_mode
+        self.input_size = input_size
+        self.mask_dict: Dict[str, torch.Tensor] = {}
+        self.module = None
+        self.mask_step = 0
+        self.baseline_nonzero = 0
+        self.total_params = 0
+        self.adjusted_growth = 0
+        self.adjustments = []
+        self.name2prune_rate = {}
+        self.stats = LayerStats()
+        self._pushed_engine = None
+
+    # ---- properties -------------------------------------------------------------------------
+    @property
+    def prune_rate(self) -> float:
+        return self.prune_rate_decay.get_dr()
+
+    # ---- setup (core.py:220-248, 386-423) ---------------------------------------------------
+    def add_module(self, module: nn.Module):
+        self.module = module
+        torch.rand(*self.input_size)            # RNG draw of the dense-FLOPs probe (core.py:229,371)
+        for name, weight in module.named_parameters():
+            self.mask_dict[name] = torch.zeros_like(weight, dtype=torch.float32, requires_grad=False)
+        for name in [n for n in self.mask_dict if "bias" in n]:       # core.py:239-240
+            self.mask_dict.pop(name)
+        for name, sub in module.named_modules():                      # core.py:241-244
+            if isinstance(sub, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                self.mask_dict.pop(name + ".weight", None)
+        init_registry[self.sparse_init](self)
+        self._to_module_device()
+        self.apply_mask()
+        self.stats.total_nonzero = self.baseline_nonzero
+        self.stats.total_zero = self.total_params - self.baseline_nonzero
+        torch.rand(*self.input_size)            # RNG draw of the sparse-FLOPs log line (core.py:248,384)
+        logging.info(f"Achieved sparsity at init (w/o BN, bias): {self.baseline_nonzero / self.total_params:.4f}")
+
+    def _to_module_device(self):
+        for name, weight in self.module.named_parameters():
+            if name in self.mask_dict:
+                self.mask_dict[name] = self.mask_dict[name].to(weight.device)
+
+    def _push_masks(self):
+        """Hand the current masks to the engine (flat, ones for unmasked parameters)."""
+        eng = getattr(self.module, "_engine", None)
+        if eng is None:
+            return
+        parts = []
+        for name, weight in self.module.named_parameters():
+            mk = self.mask_dict.get(name)
+            parts.append((mk if mk is not None else torch.ones_like(weight)).reshape(-1).float())
+        eng.set_masks(torch.cat(parts).contiguous())
+        self._pushed_engine = eng
+
+    # ---- per-step (core.py:271-289, 671-702) ------------------------------------------------
+    @torch.no_grad()
+    def apply_mask(self):
+        for name, weight in self.module.named_parameters():
+            if name in self.mask_dict:
+                weight.data.mul_(self.mask_dict[name].to(weight.dtype))
+        self._push_masks()
+
+    @torch.no_grad()
+    def apply_mask_gradients(self):
+        for name, weight in self.module.named_parameters():
+            if name in self.mask_dict and weight.grad is not None:
+                weight.grad.mul_(self.mask_dict[name])
+
+    @torch.no_grad()
+    def reset_momentum(self):
+        for name, weight in self.module.named_parameters():
+            if name not in self.mask_dict:
+                continue
+            st = self.optimizer.state[weight]
+            if "exp_avg" in st:
+                st["exp_avg"].mul_(self.mask_dict[name])
+                st["exp_avg_sq"].mul_(self.mask_dict[name])
+
+    def step(self, scaler=None):
+        """Optimiser step, then masks, then prune-rate decay (core.py:671-702).  `scaler` is accepted
+        for signature parity; GradScaler is an exact no-op on the fp32 path."""
+        eng = getattr(self.module, "_engine", None)
+        if eng is not None and self._pushed_engine is not eng:
+            self._push_masks()                  # engine was created after add_module()
+        self.optimizer.step()
+        if eng is None or not getattr(self.optimizer, "applies_engine_mask", False):
+            self.apply_mask()                   # otherwise fused into the engine's Adam kernel
+        if not self.dense_gradients:
+            self.reset_momentum()
+        self.prune_rate_decay.step(self.mask_step)
+        self.mask_step += 1
+
+    # ---- topology update (core.py:425-464, 250-269, 713-801) ----------------------------------
+    def gather_statistics(self):
+        variance, nonzeros, zeros = {}, {}, {}
+        tot_var, tot_nz, tot_z = 0.0, 0, 0
+        redist = redistribute_registry[self.redistribution_mode]
+        for name, weight in self.module.named_parameters():
+            if name not in self.mask_dict:
+                continue
+            mask = self.mask_dict[name]
+            variance[name] = redist(self, name, weight, mask)
+            if not np.isnan(variance[name]):
+                tot_var += variance[name]
+            nonzeros[name] = int((mask == 1).sum().int().item())
+            zeros[name] = int((mask == 0).sum().int().item())
+            tot_nz += nonzeros[name]
+            tot_z += zeros[name]
+        assert tot_var, "Total variance is zero!"
+        for name in variance:
+            variance[name] /= tot_var
+        self.stats = LayerStats(variance_dict=variance, nonzeros_dict=nonzeros, zeros_dict=zeros,
+                                total_variance=tot_var, total_nonzero=tot_nz, total_zero=tot_z)
+
+    def adjust_prune_rate(self):
+        for name, mask in self.mask_dict.items():
+            self.name2prune_rate[name] = self.prune_rate
+            sparsity = self.stats.zeros_dict[name] / mask.numel()
+            if sparsity < 0.2:
+                expected = 1.0 / len(self.stats.variance_dict)
+                if expected / self.stats.variance_dict[name] < 1.0:
+                    self.name2prune_rate[name] = min(sparsity, self.name2prune_rate[name])
+
+    @torch.no_grad()
+    def truncate_weights(self):
+        self.gather_statistics()
+        self.adjust_prune_rate()
+        prune = prune_registry[self.prune_mode]
+        for name, weight in self.module.named_parameters():
+            if name not in self.mask_dict:
+                continue
+            new_mask = prune(self, self.mask_dict[name], weight, name)
+            removed = self.stats.nonzeros_dict[name] - int(new_mask.sum().item())
+            self.stats.total_removed += removed
+            self.stats.removed_dict[name] = removed
+            self.mask_dict[name] = new_mask
+        total_nonzero_new = 0
+        if self.growth_mode == "none":
+            total_nonzero_new = self.stats.total_nonzero - self.stats.total_removed
+        else:
+            grow = grow_registry[self.growth_mode]
+            for name, weight in self.module.named_parameters():
+                if name not in self.mask_dict:
+                    continue
+                new_mask = grow(self, name, self.stats.removed_dict[name], weight)
+                total_nonzero_new += new_mask.sum().item()
+                self.mask_dict.pop(name)
+                self.mask_dict[name] = new_mask.float()
+        self.apply_mask()
+        if not self.dense_gradients:
+            self.reset_momentum()
+            self.apply_mask_gradients()
+        self.mask_step += 1
+        self.adjustments.append(self.baseline_nonzero - total_nonzero_new)
+        self.adjusted_growth = 0.25 * self.adjusted_growth + 0.75 * self.adjustments[-1] + np.mean(self.adjustments)
+        self.gather_statistics()
+
+    def update_connections(self):
+        self.truncate_weights()
+
+    # ---- checkpoint surface (core.py:495-506, 660-669) -----------------------------------------
+    def state_dict(self):
+        return {"baseline_nonzero": self.baseline_nonzero, "masks": self.mask_dict, "mask_step": self.mask_step,
+                "total_params": self.total_params}
+
+    def load_state_dict(self, sd):
+        self.baseline_nonzero, self.mask_step, self.total_params = sd["baseline_nonzero"], sd["mask_step"], sd["total_params"]
+        self.mask_dict = dict(sd["masks"])
+        self._to_module_device()
+        self.apply_mask()

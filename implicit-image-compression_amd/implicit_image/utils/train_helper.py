@@ -1,0 +1,150 @@
+"""Step harness with the reference's signatures (reference: implicit_image/utils/train_helper.py).
+
+  train_epoch(model, optim, grid, img, **kwargs) -> float          (:132-185)
+  eval_epoch(model, grid, img, **kwargs) -> (pred, loss, PSNR, PSNR_8bit)   (:41-59)
+  get_optimizer_lr_scheduler(model, optim_cfg, quantize_mode=False)  (:69-86)
+  setup_mask(model, optim, masking_cfg)                               (:89-129)
+  get_device(device_str)                                               (:62-66)
+
+One `train_epoch` is one full-batch fit step executed by the HIP engine: forward + MSE + backward
+(sf_forward_backward) and Adam(+mask) (sf_adam_step through the optimiser facade).
+"""
+import math
+from typing import Dict, Tuple
+
+import torch
+from torch.nn import Module, functional as F
+from torch.optim import Optimizer
+
+from ..pipeline.masking import Masking, decay_registry
+
+
+class EngineAdam(Optimizer):
+    """torch.optim.Optimizer facade over the engine's fused Adam kernel (Seam 3).
+
+    `state[p]["exp_avg"/"exp_avg_sq"]` are views of the engine's moment buffers,
+    `defaults["lr"]` / `param_groups[0]["lr"]` behave as in torch.optim.Adam (StepLR edits them),
+    `zero_grad()` is a no-op (the engine overwrites the gradient every backward)."""
+
+    applies_engine_mask = True
+
+    def __init__(self, model: Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0, amsgrad: bool = False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("EngineAdam supports weight_decay=0, amsgrad=False (reference defaults)")
+        if tuple(betas) != (0.9, 0.999) or eps != 1e-8:
+            raise NotImplementedError("EngineAdam uses torch.optim.Adam's default betas/eps (conf/optim/adam.yaml)")
+        self.model = model
+        super().__init__(model.parameters(), dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+        self._bound = None
+
+    def _bind_state(self, eng):
+        if self._bound is eng:
+            return
+        m, v = eng.view("exp_avg"), eng.view("exp_avg_sq")
+        off = 0
+        for p in self.model.parameters():
+            n = p.numel()
+            st = self.state[p]
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = m[off:off + n].view(p.shape)
+            st["exp_avg_sq"] = v[off:off + n].view(p.shape)
+            off += n
+        self._bound = eng
+
+    def zero_grad(self, set_to_none: bool = True):
+        return None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        eng = getattr(self.model, "_engine", None)
+        if eng is None:
+            raise RuntimeError("EngineAdam.step() before any forward/backward: the engine is created by train_epoch")
+        self._bind_state(eng)
+        eng.adam_step(float(self.param_groups[0]["lr"]))
+        for p in self.model.parameters():
+            self.state[p]["step"] += 1
+        return None
+
+
+def get_device(device_str: str) -> torch.device:
+    if device_str == "cuda" and torch.cuda.is_available():
+        return torch.device(device_str)
+    return torch.device("cpu")
+
+
+def get_optimizer_lr_scheduler(model: Module, optim_cfg: Dict, quantize_mode: bool = False
+                               ) -> Tuple[Optimizer, torch.optim.lr_scheduler._LRScheduler]:
+    """Adam (conf/optim/adam.yaml) + StepLR(2000, 0.5), StepLR(1000, 0.5) in the quantise phase."""
+    name = optim_cfg["name"] if isinstance(optim_cfg, dict) else optim_cfg.name
+    kwargs = {k: v for k, v in dict(optim_cfg).items() if k != "name"}
+    if name != "adam":
+        raise NotImplementedError(f"optimiser '{name}': only 'adam' is on the accelerated path")
+    optim = EngineAdam(model, **kwargs)
+    lr_scheduler = torch.optim.lr_scheduler.StepLR(optim, 1000 if quantize_mode else 2000, gamma=0.5)
+    return optim, lr_scheduler
+
+
+def _cfg_get(cfg, key, default=None):
+    return cfg.get(key, default) if hasattr(cfg, "get") else getattr(cfg, key, default)
+
+
+def setup_mask(model: Module, optim: Optimizer, masking_cfg=None) -> Masking:
+    """Masking instance wrapping `model`, or None for dense fits (reference :89-129)."""
+    if not masking_cfg or _cfg_get(masking_cfg, "dense"):
+        return None
+    schedule = _cfg_get(masking_cfg, "decay_schedule")
+    if schedule not in decay_registry:
+        raise NotImplementedError(f"decay_schedule '{schedule}' is outside the accelerated RigL path")
+    decay = decay_registry[schedule](prune_rate=_cfg_get(masking_cfg, "prune_rate"),
+                                     T_max=_cfg_get(masking_cfg, "end_when"))
+    mask = Masking(optim, decay, input_size=(1, 1, 2), density=_cfg_get(masking_cfg, "density"),
+                   dense_gradients=_cfg_get(masking_cfg, "dense_gradients"),
+                   sparse_init=_cfg_get(masking_cfg, "sparse_init"), prune_mode=_cfg_get(masking_cfg, "prune_mode"),
+                   growth_mode=_cfg_get(masking_cfg, "growth_mode"),
+                   redistribution_mode=_cfg_get(masking_cfg, "redistribution_mode"))
+    model.train()
+    mask.add_module(model)
+    return mask
+
+
+def train_epoch(model: Module, optim: Optimizer, grid, img, **kwargs) -> float:
+    """One full-batch optimiser step; returns the loss of the step like `train_loss.item()`."""
+    mask: Masking = kwargs.get("mask")
+    pbar = kwargs.get("pbar")
+    lr_scheduler = kwargs.get("lr_scheduler")
+    criterion = kwargs.get("criterion", F.mse_loss)
+    if criterion is not F.mse_loss:
+        raise NotImplementedError("the engine fuses F.mse_loss (reduction='mean'); other criteria are not supported")
+    if kwargs.get("preconditioner") is not None:
+        raise NotImplementedError("preconditioners (EKFAC) are dead code in the reference and not supported")
+    # kwargs 'scaler' / 'context' are accepted and ignored: autocast is never entered by the reference
+    # (train_helper.py:141) and GradScaler is an exact no-op on fp32 gradients.
+    model.train()
+    optim.zero_grad()
+    eng = model.engine(grid, img)
+    sse = eng.forward_backward(sync=True)
+    loss = sse / (img.shape[0] * img.shape[1] * img.shape[2])
+    if mask:
+        mask.step(kwargs.get("scaler"))
+    else:
+        optim.step()
+    if pbar:
+        pbar.update(1)
+    if lr_scheduler:
+        lr_scheduler.step()
+    return loss
+
+
+@torch.no_grad()
+def eval_epoch(model: Module, grid, img, **kwargs) -> Tuple[torch.Tensor, float, float, float]:
+    model.eval()
+    eng = model.engine(grid, img)
+    pred, sse = eng.forward(want_pred=True, want_sse=True)
+    test_loss = sse / img.numel()
+    test_PSNR = 10 * math.log10(1 / test_loss)
+    img_8bit = (img * 255).int()
+    pred_8bit = (pred * 255).int()
+    mse_8bit = ((img_8bit - pred_8bit) ** 2).float().mean()
+    test_PSNR_8bit = 10 * torch.log10(255 ** 2 / mse_8bit)
+    return pred, test_loss, test_PSNR, test_PSNR_8bit.item()

@@ -1,0 +1,129 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/siren_fit.h declares;
+the host mirror reproduces the reference's init, ERK masks, prune/grow step, cosine decay and the
+full RigL topology trace bit-exactly (index paths).  No compute calls into the library here."""
+import numpy as np
+import pytest
+import torch
+
+from implicit_image import _engine
+from implicit_image.models import registry
+from implicit_image.pipeline.masking import CosineDecay, Masking
+from implicit_image.utils.train_helper import get_optimizer_lr_scheduler, setup_mask
+
+
+class Cfg(dict):
+    __getattr__ = dict.get
+
+
+RIGL = dict(name="RigL", sparse_init="erdos-renyi-kernel", dense_gradients=True, growth_mode="absolute-gradient",
+            prune_mode="magnitude", redistribution_mode="none", dense=False, prune_rate=0.1,
+            decay_schedule="cosine", end_when=1500, interval=20)
+
+
+def _bits(mask):
+    return np.packbits(np.concatenate([mask.mask_dict[n].cpu().numpy().ravel().astype(np.uint8)
+                                       for n in _names(mask)]))
+
+
+def _names(mask):
+    return [n for n, _ in mask.module.named_parameters() if n in mask.mask_dict]
+
+
+def _flat(model, grad=False):
+    return np.concatenate([(p.grad if grad else p).detach().cpu().numpy().ravel() for p in model.parameters()])
+
+
+def test_library_exports_declared_symbols():
+    lib = _engine.load_library()
+    names = _engine.exported_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.sf_abi_version() == _engine.SF_ABI_VERSION
+
+
+def test_create_rejects_bad_config_without_gpu():
+    import ctypes as C
+    lib = _engine.load_library()
+    cfg = _engine.sf_config(_engine.SF_ABI_VERSION, 8, 8, 0, 0, 2, 3, 100, 4, 50.0, 30.0, 1, 1, 0.9, 0.999, 1e-8, 0,
+                            None, 0)
+    h = C.c_void_p()
+    assert lib.sf_create(C.byref(cfg), C.byref(h)) == -1          # SF_ERR_INVALID: hidden=100 unsupported
+    assert b"hidden" in lib.sf_last_error()
+    cfg.abi_version = 99
+    assert lib.sf_create(C.byref(cfg), C.byref(h)) == -1
+    assert lib.sf_create(None, C.byref(h)) == -1
+
+
+def test_model_init_matches_reference(golden):
+    for name, hidden, depth in (("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8)):
+        torch.manual_seed(0)
+        m = registry["siren"](depth=depth, hidden_size=hidden, first_omega_0=50, hidden_omega_0=30)
+        assert np.array_equal(_flat(m), golden(name)["init"])
+        assert [n for n, _ in m.named_parameters()][:2] == ["layers.0.linear.weight", "layers.0.linear.bias"]
+
+
+@pytest.mark.parametrize("hidden,depth,density", [(256, 8, 0.1), (64, 4, 0.5), (128, 8, 0.5)])
+def test_erk_masks_bit_exact(golden, hidden, depth, density):
+    e = golden("erk_masks")
+    key = f"{hidden}x{depth}_d{density}"
+    torch.manual_seed(0)
+    m = registry["siren"](depth=depth, hidden_size=hidden, first_omega_0=50, hidden_omega_0=30)
+    opt, _ = get_optimizer_lr_scheduler(m, Cfg(name="adam", lr=3e-4))
+    mask = setup_mask(m, opt, Cfg(density=density, **RIGL))
+    assert np.array_equal(_bits(mask), e[key + "_bits"])
+    assert [int(mask.mask_dict[n].sum()) for n in _names(mask)] == e[key + "_nnz"].tolist()
+    assert mask.baseline_nonzero == int(e[key + "_baseline_nonzero"]) and mask.total_params == int(e[key + "_total_params"])
+    assert np.array_equal(torch.rand(4).numpy(), e[key + "_rng_after"])       # generator position
+    assert np.array_equal(_flat(m), e[key + "_params_after"])                 # apply_mask on the weights
+
+
+@pytest.mark.parametrize("hidden,depth,density", [(64, 4, 0.5), (256, 8, 0.1)])
+def test_truncate_weights_bit_exact(golden, hidden, depth, density):
+    """One update_connections(): (w, grad, mask, rate) -> (mask', w') identical to the reference."""
+    d = golden(f"truncate_{hidden}x{depth}")
+    torch.manual_seed(0)
+    m = registry["siren"](depth=depth, hidden_size=hidden, first_omega_0=50, hidden_omega_0=30)
+    opt, _ = get_optimizer_lr_scheduler(m, Cfg(name="adam", lr=3e-4))
+    mask = setup_mask(m, opt, Cfg(density=density, **RIGL))
+    # load the reference's pre-update state
+    off = 0
+    mbits = np.unpackbits(d["mask_in"])
+    moff = 0
+    for n, p in m.named_parameters():
+        k = p.numel()
+        p.data = torch.tensor(d["w_in"][off:off + k]).view(p.shape)
+        p.grad = torch.tensor(d["g_in"][off:off + k]).view(p.shape)
+        off += k
+        if n in mask.mask_dict:
+            mask.mask_dict[n] = torch.tensor(mbits[moff:moff + k].astype(np.float32)).view(p.shape)
+            moff += k
+    mask.mask_step = int(d["mask_step_in"])
+    for s in range(mask.mask_step):           # replay the decay to the reference's position
+        mask.prune_rate_decay.step(s)
+    assert mask.prune_rate == pytest.approx(float(d["rate_in"]), rel=0, abs=1e-15)
+    mask.update_connections()
+    assert np.array_equal(_bits(mask), d["mask_out"])
+    assert np.array_equal(_flat(m), d["w_out"])
+    assert mask.mask_step == int(d["mask_step_out"])
+    assert [mask.stats.nonzeros_dict[n] for n in _names(mask)] == d["nnz_out"].tolist()
+
+
+def test_cosine_decay_sequence(golden):
+    d = golden("cosine_decay")
+    dec = CosineDecay(prune_rate=float(d["prune_rate"]), T_max=int(d["T_max"]))
+    seq, mask_step = [], 0
+    for i in range(100):
+        dec.step(mask_step)
+        mask_step += 1
+        if i <= int(d["T_max"]) and i % int(d["interval"]) == 0:
+            mask_step += 1
+        seq.append(dec.get_dr())
+    assert np.allclose(np.array(seq), d["seq"], rtol=0, atol=1e-16)
+
+
+def test_masking_registry_errors():
+    with pytest.raises(AssertionError):
+        Masking(None, None, sparse_init="nope")
+    with pytest.raises(AssertionError):
+        Masking(None, None, sparse_init="erdos-renyi-kernel", growth_mode="nope")

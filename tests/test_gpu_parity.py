@@ -1,0 +1,305 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP engine, called through the C ABI
+(ctypes stub in implicit_image/_engine.py), against the CPU oracle on the same seeded inputs and
+against golden vectors minted from the real reference.
+
+Tolerances (all stated where used):
+  forward, fp16 operands   : |dpred| <= 3e-4 abs        (operand rounding 2^-11, f32 accumulate)
+  forward, bf16 operands   : |dpred| <= 3e-3 abs        (2^-8)
+  gradients, bf16 backward : per-layer and total L2 error <= 1.5e-2 relative
+  PSNR after equal steps   : |dPSNR| <= 0.05 dB          (BASELINE.json north star)
+  index / mask paths       : bit-exact
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import siren_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(H, W, hidden, depth, dtype="f16", params=None, img=None, **kw):
+    from implicit_image._engine import SirenEngine
+    eng = SirenEngine(H, W, hidden, depth, compute_dtype=dtype, **kw)
+    gh, gw = so.grid_vectors(H, W)
+    eng.set_coords(gh.cuda(), gw.cuda())
+    if params is not None:
+        eng.set_params(torch.tensor(so.flatten(params)).cuda())
+    if img is not None:
+        r0, r1 = eng.row_begin, eng.row_end
+        eng.set_target(img[r0:r1].contiguous().cuda())
+    return eng
+
+
+@pytest.mark.parametrize("name,hidden,depth", [("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8),
+                                               ("grads_128x6_48", 128, 6)])
+@pytest.mark.parametrize("dtype,tol", [("f16", 3e-4), ("bf16", 3e-3)])
+def test_forward_and_gradients_vs_reference_golden(golden, name, hidden, depth, dtype, tol):
+    d = golden(name)
+    H, W, _ = d["img"].shape
+    p = so.unflatten(d["init"], hidden, depth)
+    eng = _engine(H, W, hidden, depth, dtype, p, torch.tensor(d["img"]))
+    pred, sse = eng.forward()
+    assert np.abs(pred.cpu().numpy() - d["pred"]).max() <= tol
+    assert abs(sse / (3 * H * W) - float(d["loss"])) <= 50 * tol * float(d["loss"])
+    eng.forward_backward()
+    g = eng.get_grads().cpu().numpy()
+    ref = d["grads"]
+    assert np.linalg.norm(g - ref) <= 1.5e-2 * np.linalg.norm(ref)
+    off = 0
+    for fin, fout in so.layer_dims(hidden, depth):
+        for n in (fin * fout, fout):
+            a, b = g[off:off + n], ref[off:off + n]
+            off += n
+            assert np.linalg.norm(a - b) <= 1.5e-2 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("H,W,hidden,depth", [(5, 7, 32, 3), (1, 1, 64, 2), (17, 300, 64, 4), (33, 31, 128, 5)])
+def test_ragged_and_tiny_grids(H, W, hidden, depth):
+    """Pixel counts that are not multiples of the 256-pixel workgroup tile, down to one pixel."""
+    p = so.siren_init(hidden, depth, seed=1)
+    img = so.synthetic_image(H, W, seed=2)
+    grid = so.get_grid(H, W)
+    loss, sse, grads = so.loss_and_grads(p, grid, img)
+    eng = _engine(H, W, hidden, depth, "f16", p, img)
+    pred, sse_e = eng.forward()
+    assert (pred.cpu() - so.forward(p, grid)).abs().max().item() <= 3e-4
+    assert abs(sse_e - sse) <= 2e-3 * sse
+    eng.forward_backward()
+    g, ref = eng.get_grads().cpu().numpy(), so.flatten(grads)
+    assert np.linalg.norm(g - ref) <= 1.5e-2 * np.linalg.norm(ref)
+
+
+def test_chunking_is_a_summation_order_change_only():
+    H, W, hidden, depth = 48, 56, 128, 6
+    p = so.siren_init(hidden, depth, seed=0)
+    img = so.synthetic_image(H, W, seed=7)
+    a = _engine(H, W, hidden, depth, "f16", p, img)
+    b = _engine(H, W, hidden, depth, "f16", p, img, chunk_pixels=512)
+    sa, sb = a.forward_backward(), b.forward_backward()
+    assert abs(sa - sb) <= 1e-6 * sa
+    ga, gb = a.get_grads(), b.get_grads()
+    assert (ga - gb).norm().item() <= 1e-5 * ga.norm().item()
+
+
+def test_run_to_run_determinism():
+    """No float atomics anywhere: two fits from the same state are bit-identical."""
+    H, W, hidden, depth = 64, 64, 64, 4
+    p = so.siren_init(hidden, depth, seed=0)
+    img = so.synthetic_image(H, W, seed=3)
+    outs = []
+    for _ in range(2):
+        eng = _engine(H, W, hidden, depth, "f16", p, img)
+        losses = eng.step([3e-4] * 25, want_loss=True)
+        outs.append((losses, eng.get_params().cpu().numpy()))
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_adam_kernel_matches_torch_op_order():
+    hidden, depth = 64, 4
+    p = so.siren_init(hidden, depth, seed=0)
+    eng = _engine(8, 8, hidden, depth, "f16", p)
+    opt = so.Adam(p)
+    gen = torch.Generator().manual_seed(5)
+    for t in range(3):
+        grads = [torch.randn(q.shape, generator=gen) * 1e-3 for q in p]
+        eng.set_grads(torch.tensor(so.flatten(grads)).cuda())
+        eng.adam_step(3e-4)
+        opt.step(p, grads, lr=3e-4)
+    got = eng.get_params().cpu().numpy()
+    assert np.abs(got - so.flatten(p)).max() <= 1e-7           # fp32, same op order
+    m, v, step = eng.get_adam_state()
+    assert step == 3
+    assert np.abs(m.cpu().numpy() - so.flatten(opt.m)).max() <= 1e-9
+
+
+def test_loss_curve_tracks_oracle_then_psnr_parity_config1(golden):
+    """BASELINE.json config 1: SIREN 64x4 on the 256x256 formula image, 1000 full-batch steps,
+    against the loss curve and PSNR the REAL reference produced (tests/golden/hot_64x4_256.npz)."""
+    d = golden("hot_64x4_256")
+    H = W = 256
+    img = so.synthetic_image(H, W)
+    p = so.unflatten(d["init"], 64, 4)
+    eng = _engine(H, W, 64, 4, "f16", p, img)
+    lrs = [so.step_lr(3e-4, t) for t in range(1000)]
+    losses = np.array(eng.step(lrs, want_loss=True))
+    ref = d["losses"]
+    assert np.max(np.abs(losses[:50] - ref[:50]) / ref[:50]) <= 2e-3       # before trajectories decorrelate
+    assert np.median(np.abs(losses - ref) / ref) <= 2e-2
+    _, sse = eng.forward(want_pred=False)
+    psnr = 10 * math.log10(3 * H * W / sse)
+    assert abs(psnr - float(d["psnr"])) <= 0.05, (psnr, float(d["psnr"]))
+
+
+def test_short_run_256x8_vs_reference(golden):
+    """20 steps of the metric model (256x8) on a 64x64 image.  This heavily over-parameterised early
+    phase amplifies ANY perturbation (an fp32 run with another thread count drifts by percents), so the
+    reference curve is matched tightly only for the first steps; the whole curve is matched against the
+    engine NUMERICS MODEL (oracle/engine_model.py: same rounding points, torch CPU arithmetic)."""
+    from oracle import engine_model as em
+    d = golden("short_256x8_64")
+    p = so.unflatten(d["init"], 256, 8)
+    img = torch.tensor(d["img"])
+    eng = _engine(64, 64, 256, 8, "f16", p, img)
+    losses = np.array(eng.step([3e-4] * 20, want_loss=True))
+    assert np.max(np.abs(losses[:4] - d["losses"][:4]) / d["losses"][:4]) <= 2e-3
+    grid, opt, model = so.get_grid(64, 64), so.Adam(p), []
+    for t in range(20):
+        loss, _, grads, _ = em.loss_and_grads(p, grid, img)
+        opt.step(p, grads, lr=3e-4)
+        model.append(loss)
+    assert np.max(np.abs(losses - np.array(model)) / np.array(model)) <= 2e-2, (losses, model)
+
+
+@pytest.mark.parametrize("name,hidden,depth", [("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8)])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_engine_equals_its_numerics_model(golden, name, hidden, depth, dtype):
+    """Engine vs oracle/engine_model.py (identical rounding points): what remains is fp32 summation
+    order, v_sin/v_cos vs libm, and the occasional bf16 tie flipping: <= 2e-3 relative."""
+    from oracle import engine_model as em
+    d = golden(name)
+    H, W, _ = d["img"].shape
+    p = so.unflatten(d["init"], hidden, depth)
+    img = torch.tensor(d["img"])
+    loss, sse, grads, pred = em.loss_and_grads(p, so.get_grid(H, W), img, fwd=dtype)
+    eng = _engine(H, W, hidden, depth, dtype, p, img)
+    pe, sse_e = eng.forward()
+    assert (pe.cpu() - pred).abs().max().item() <= (5e-5 if dtype == "f16" else 4e-4)
+    assert abs(sse_e - sse) <= 1e-4 * sse
+    eng.forward_backward()
+    g, ref = eng.get_grads().cpu().numpy(), so.flatten(grads)
+    assert np.linalg.norm(g - ref) <= 2e-3 * np.linalg.norm(ref)
+
+
+def test_masks_are_applied_inside_the_step():
+    H, W, hidden, depth = 32, 32, 64, 4
+    p = so.siren_init(hidden, depth, seed=0)
+    img = so.synthetic_image(H, W, seed=9)
+    eng = _engine(H, W, hidden, depth, "f16", p, img)
+    gen = torch.Generator().manual_seed(1)
+    masks, flat = [], []
+    for q in p:
+        mk = (torch.rand(q.shape, generator=gen) < 0.5).float() if q.dim() == 2 else torch.ones_like(q)
+        masks.append(mk if q.dim() == 2 else None)
+        flat.append(mk.reshape(-1))
+        q.mul_(mk)
+    eng.set_params(torch.tensor(so.flatten(p)).cuda())
+    eng.set_masks(torch.cat(flat).cuda())
+    opt = so.Adam(p)
+    grid = so.get_grid(H, W)
+    ref = [so.train_epoch(p, opt, grid, img, t, masks=masks) for t in range(10)]
+    got = eng.step([3e-4] * 10, want_loss=True)
+    assert np.max(np.abs(np.array(got) - np.array(ref)) / np.array(ref)) <= 2e-3
+    w = eng.get_params().cpu()
+    assert torch.all(w[torch.cat(flat) == 0] == 0)               # bit-exact: masked weights stay zero
+
+
+def test_pixel_split_handles_compose():
+    """Row-sharded handles (pixel-split mode): SSE and gradients of the shards add up to the
+    full-image values — the property the RCCL all-reduce path relies on."""
+    H, W, hidden, depth = 64, 48, 64, 4
+    p = so.siren_init(hidden, depth, seed=0)
+    img = so.synthetic_image(H, W, seed=4)
+    full = _engine(H, W, hidden, depth, "f16", p, img)
+    sse = full.forward_backward()
+    g = full.get_grads()
+    tot, gs = 0.0, torch.zeros_like(g)
+    for r0, r1 in ((0, 20), (20, 64)):
+        part = _engine(H, W, hidden, depth, "f16", p, img, row_begin=r0, row_end=r1)
+        tot += part.forward_backward()
+        gs += part.get_grads()
+    assert abs(tot - sse) <= 1e-6 * sse
+    assert (gs - g).norm().item() <= 1e-5 * g.norm().item()
+
+
+def test_full_size_grid_properties():
+    """BASELINE metric shape (256x8) on a 2048x2048 grid: properties that need no oracle run —
+    finite loss, gradient of a doubled residual doubles (linearity of the backward in dL/dout),
+    loss decreases over a few steps."""
+    H = W = 2048
+    p = so.siren_init(256, 8, seed=0)
+    ys = torch.linspace(0, 1, H, device="cuda")[:, None, None]
+    xs = torch.linspace(0, 1, W, device="cuda")[None, :, None]
+    k = torch.tensor([1.0, 2.0, 3.0], device="cuda")
+    img = (0.5 + 0.25 * torch.sin(12 * xs * k) + 0.25 * torch.cos(9 * ys * k)).contiguous()
+    eng = _engine(H, W, 256, 8, "f16", p)
+    eng.set_target(img)
+    pred, sse0 = eng.forward()
+    assert math.isfinite(sse0) and pred.min().item() > -2 and pred.max().item() < 3
+    eng.forward_backward()
+    g1 = eng.get_grads().clone()
+    img2 = (2 * img - pred).contiguous()          # residual (pred - img2) = 2 * (pred - img) ... negated twice
+    eng.set_target(img2)
+    eng.forward_backward()
+    g2 = eng.get_grads()
+    assert (g2 - 2 * g1).norm().item() <= 2e-2 * (2 * g1).norm().item()   # bf16 rounding of dL/dout differs
+    eng.set_target(img)
+    losses = eng.step([3e-4] * 5, want_loss=True)
+    assert losses[-1] < losses[0]
+
+
+def test_host_mirror_train_and_eval_epoch():
+    """Reference-shaped API: registry['siren'] + get_optimizer_lr_scheduler + train_epoch/eval_epoch."""
+    from implicit_image.data import get_grid
+    from implicit_image.models import registry
+    from implicit_image.utils.train_helper import eval_epoch, get_optimizer_lr_scheduler, train_epoch
+    H = W = 64
+    torch.manual_seed(0)
+    model = registry["siren"](depth=4, hidden_size=64, first_omega_0=50, hidden_omega_0=30).to("cuda")
+    img = so.synthetic_image(H, W, seed=3)
+    grid = get_grid(H, W)
+    optim, sched = get_optimizer_lr_scheduler(model, dict(name="adam", lr=3e-4))
+    p = so.siren_init(64, 4, seed=0)
+    opt = so.Adam(p)
+    got = [train_epoch(model, optim, grid.cuda(), img.cuda(), lr_scheduler=sched) for _ in range(10)]
+    ref = [so.train_epoch(p, opt, so.get_grid(H, W), img, t) for t in range(10)]
+    assert np.max(np.abs(np.array(got) - np.array(ref)) / np.array(ref)) <= 2e-3
+    pred, loss, psnr, psnr8 = eval_epoch(model, grid.cuda(), img.cuda())
+    _, l_ref, psnr_ref, psnr8_ref = so.eval_epoch(p, so.get_grid(H, W), img)
+    assert abs(psnr - psnr_ref) <= 0.05 and abs(psnr8 - psnr8_ref) <= 0.1
+    # parameters are live views of engine state
+    w0 = dict(model.named_parameters())["layers.1.linear.weight"]
+    assert w0.grad is not None and w0.grad.shape == w0.shape
+    assert optim.state[w0]["exp_avg"].abs().sum().item() > 0
+
+
+def test_rigl_run_vs_reference_golden(golden):
+    """RigL (ERK 0.5, prune 0.1, cosine) 120 steps on 64x64: same initial masks bit-exactly; the
+    topology then evolves from bf16-rounded gradients, so the end state is compared by PSNR/density."""
+    from implicit_image.data import get_grid
+    from implicit_image.models import registry
+    from implicit_image.utils.train_helper import (eval_epoch, get_optimizer_lr_scheduler, setup_mask, train_epoch)
+    d = golden("rigl_64x4_64")
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+    H = W = 64
+    torch.manual_seed(0)
+    model = registry["siren"](depth=4, hidden_size=64, first_omega_0=50, hidden_omega_0=30).to("cuda")
+    optim, sched = get_optimizer_lr_scheduler(model, Cfg(name="adam", lr=3e-4))
+    mcfg = Cfg(name="RigL", density=0.5, sparse_init="erdos-renyi-kernel", dense_gradients=True,
+               growth_mode="absolute-gradient", prune_mode="magnitude", redistribution_mode="none", dense=False,
+               prune_rate=0.1, decay_schedule="cosine", end_when=90, interval=10)
+    mask = setup_mask(model, optim, mcfg)
+    names = [n for n, _ in model.named_parameters() if n in mask.mask_dict]
+    bits = np.packbits(np.concatenate([mask.mask_dict[n].cpu().numpy().ravel().astype(np.uint8) for n in names]))
+    assert np.array_equal(bits, d["mask0"])
+    img, grid = torch.tensor(d["img"]).cuda(), get_grid(H, W).cuda()
+    losses, rates = [], []
+    for i in range(120):
+        losses.append(train_epoch(model, optim, grid, img, lr_scheduler=sched, mask=mask))
+        if i <= mcfg.end_when and i % mcfg.interval == 0:
+            mask.update_connections()
+        rates.append(mask.prune_rate)
+    assert np.allclose(rates, d["rates"], rtol=0, atol=1e-12)            # schedule is exact
+    assert mask.mask_step == int(d["mask_step"])
+    assert np.max(np.abs(np.array(losses[:10]) - d["losses"][:10]) / d["losses"][:10]) <= 3e-3
+    assert abs(mask.stats.total_density - float(d["density"][-1])) <= 0.01
+    _, _, psnr, _ = eval_epoch(model, grid, img)
+    assert abs(psnr - float(d["psnr"])) <= 0.3     # different (equally valid) topology after 10 updates
+    for n, w in model.named_parameters():
+        if n in mask.mask_dict:
+            assert torch.all(w.data[mask.mask_dict[n] == 0] == 0)
