@@ -54,6 +54,7 @@ def cpu_baseline(hidden, depth, size, warm=1, timed=3):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)          # the GPU box grants ~16 host cores per GPU; more threads only thrash
     torch.set_num_threads(cores)
     p = so.siren_init(hidden, depth, seed=0)
     img = so.synthetic_image(size, size)
