@@ -151,7 +151,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"siren_{args.hidden}x{args.depth}_fit_step_{H}x{W}x3_grid", "image": f"{H}x{W}x3",
                        "hidden": args.hidden, "depth": args.depth, "sharding": f"per-image x{world}",
-                       "chunk_pixels": eng.npix if args.chunk == 0 and eng.npix < (1 << 20) else (args.chunk or 1 << 20)},
+                       "chunk_pixels": eng.npix if args.chunk == 0 and eng.npix < (1 << 22) else (args.chunk or 1 << 22)},
             "step_mfma_frac": value / world * 1e6 * F / (PEAK_BF16_TFLOPS * 1e12),
             "psnr_after_run": psnr,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -30,9 +30,9 @@ static int fail(int code, const std::string& msg) {
       return fail(SF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
   } while (0)
 
-enum KernelId { K_FWD = 0, K_BWDX, K_DW_HIDDEN, K_DW_LAST, K_DW_FIRST, K_REDUCE, K_SSE, K_ADAM, K_IMAGES, K_COUNT };
-static const char* kKernelNames[K_COUNT] = {"k_fwd",    "k_bwdx", "k_dw_hidden", "k_dw_last", "k_dw_first",
-                                            "k_reduce", "k_sse",  "k_adam",      "k_images"};
+enum KernelId { K_FWD = 0, K_BWD_HIDDEN, K_BWD_LAST, K_DW_FIRST, K_REDUCE, K_SSE, K_ADAM, K_IMAGES, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"k_fwd",    "k_bwd_hidden", "k_bwd_last", "k_dw_first",
+                                            "k_reduce", "k_sse",        "k_adam",     "k_images"};
 
 struct ProfRec {
   int id;
@@ -54,7 +54,6 @@ struct sf_engine {
   // images
   uint16_t *wf = nullptr, *wf_last = nullptr, *wb = nullptr, *wb_last = nullptr;
   f32x4* l0tab = nullptr;
-  float *bias_h = nullptr, *bias_last = nullptr;
   bool images_dirty = true;
   float wscale = 1.f;
   // data
@@ -124,8 +123,7 @@ int set_lds(K kernel, size_t bytes) {
   return SF_OK;
 }
 
-size_t fwd_lds_bytes(int WD) { return (size_t)WD * WD * 2 + (size_t)WD * 16 + (size_t)(WD < 32 ? 32 : WD) * 4 + 64; }
-size_t bwd_lds_bytes(int WD) { return (size_t)WD * WD * 2 + 64; }
+size_t fwd_lds_bytes(int WD) { return (size_t)FwdGeom(WD).PIECES * 1024 + (size_t)WD * 16 + 64; }
 
 template <int WD>
 int launch_fwd_t(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
@@ -147,16 +145,6 @@ int launch_fwd_t(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
   return SF_OK;
 }
 
-template <int WD>
-int launch_bwdx_t(sf_engine* h, const BwdArgs& a, int n_super) {
-  const size_t lds = bwd_lds_bytes(WD);
-  int rc = set_lds(k_bwdx<WD>, lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL((k_bwdx<WD>), dim3(n_super), dim3(512), lds, h->stream, a);
-  HIPCHK(hipGetLastError());
-  return SF_OK;
-}
-
 template <int ROWS, int COLS, int WR, int WC, int BSRC>
 int launch_dw_t(sf_engine* h, const DwArgs& a, int n_wg) {
   const size_t lds = (size_t)2 * (ROWS / 16 + COLS / 16) * 1024;
@@ -167,25 +155,34 @@ int launch_dw_t(sf_engine* h, const DwArgs& a, int n_wg) {
   return SF_OK;
 }
 
-// which: 0 hidden, 1 last, 2 first
-int launch_dw(sf_engine* h, int which, const DwArgs& a, int n_wg) {
+template <int JW, int IW, int WR, int WC, bool LAST>
+int launch_bwd_t(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
+  const size_t lds = (size_t)2 * 2 * (JW / 16 + IW / 16) * 1024;
+  int rc = set_lds(k_bwd<JW, IW, WR, WC, LAST>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_bwd<JW, IW, WR, WC, LAST>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+
+// fused backward of one layer: last = the out_features(<=3, padded to 32)-row layer
+int launch_bwd(sf_engine* h, bool last, const BwdLayerArgs& a, int n_wg) {
   switch (h->WD) {
-    case 32:
-      if (which == 0) return launch_dw_t<32, 32, 1, 1, 0>(h, a, n_wg);
-      if (which == 1) return launch_dw_t<32, 32, 1, 1, 0>(h, a, n_wg);
-      return launch_dw_t<32, 32, 1, 1, 1>(h, a, n_wg);
-    case 64:
-      if (which == 0) return launch_dw_t<64, 64, 2, 2, 0>(h, a, n_wg);
-      if (which == 1) return launch_dw_t<32, 64, 1, 2, 0>(h, a, n_wg);
-      return launch_dw_t<64, 32, 2, 1, 1>(h, a, n_wg);
-    case 128:
-      if (which == 0) return launch_dw_t<128, 128, 2, 4, 0>(h, a, n_wg);
-      if (which == 1) return launch_dw_t<32, 128, 1, 4, 0>(h, a, n_wg);
-      return launch_dw_t<128, 32, 4, 1, 1>(h, a, n_wg);
-    case 256:
-      if (which == 0) return launch_dw_t<256, 256, 2, 4, 0>(h, a, n_wg);
-      if (which == 1) return launch_dw_t<32, 256, 1, 8, 0>(h, a, n_wg);
-      return launch_dw_t<256, 32, 8, 1, 1>(h, a, n_wg);
+    case 32: return last ? launch_bwd_t<32, 32, 1, 1, true>(h, a, n_wg) : launch_bwd_t<32, 32, 1, 1, false>(h, a, n_wg);
+    case 64: return last ? launch_bwd_t<32, 64, 1, 2, true>(h, a, n_wg) : launch_bwd_t<64, 64, 2, 2, false>(h, a, n_wg);
+    case 128: return last ? launch_bwd_t<32, 128, 1, 4, true>(h, a, n_wg) : launch_bwd_t<128, 128, 2, 4, false>(h, a, n_wg);
+    case 256: return last ? launch_bwd_t<32, 256, 1, 8, true>(h, a, n_wg) : launch_bwd_t<256, 256, 2, 2, false>(h, a, n_wg);
+  }
+  return fail(SF_ERR_INVALID, "unsupported hidden width");
+}
+
+// weight gradient of layer 0 (no data gradient needed): contraction of delta_0 with the coordinates
+int launch_dw_first(sf_engine* h, const DwArgs& a, int n_wg) {
+  switch (h->WD) {
+    case 32: return launch_dw_t<32, 32, 1, 1, 1>(h, a, n_wg);
+    case 64: return launch_dw_t<64, 32, 2, 1, 1>(h, a, n_wg);
+    case 128: return launch_dw_t<128, 32, 4, 1, 1>(h, a, n_wg);
+    case 256: return launch_dw_t<256, 32, 8, 1, 1>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
@@ -199,16 +196,6 @@ int launch_fwd(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
-int launch_bwdx(sf_engine* h, const BwdArgs& a, int n_super) {
-  switch (h->WD) {
-    case 32: return launch_bwdx_t<32>(h, a, n_super);
-    case 64: return launch_bwdx_t<64>(h, a, n_super);
-    case 128: return launch_bwdx_t<128>(h, a, n_super);
-    case 256: return launch_bwdx_t<256>(h, a, n_super);
-  }
-  return fail(SF_ERR_INVALID, "unsupported hidden width");
-}
-
 int refresh_images(sf_engine* h) {
   if (!h->images_dirty) return SF_OK;
   ImgArgs a;
@@ -224,7 +211,7 @@ int refresh_images(sf_engine* h) {
   a.wscale = h->wscale;
   a.fwd_is_f16 = h->cfg.compute_dtype == SF_F16;
   a.wf = h->wf; a.wf_last = h->wf_last; a.wb = h->wb; a.wb_last = h->wb_last;
-  a.l0tab = h->l0tab; a.bias_h = h->bias_h; a.bias_last = h->bias_last;
+  a.l0tab = h->l0tab;
   long n = (long)(h->D - 2) * h->WD * h->WD;
   const long n_min = (long)h->WD / 16 * 64 * 8;  // also covers the small tables
   if (n < n_min) n = n_min;
@@ -242,7 +229,7 @@ double flops_fwd_px(const sf_engine* h) {
   const double W = h->WD;
   return 2.0 * (2 * W + (h->D - 2) * W * W + h->cfg.out_features * W);
 }
-double flops_bwdx_px(const sf_engine* h) {
+double flops_bwdx_px_unused(const sf_engine* h) {
   const double W = h->WD;
   return 2.0 * ((h->D - 2) * W * W + h->cfg.out_features * W);
 }
@@ -268,7 +255,6 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     fa.l0tab = h->l0tab;
     fa.wf = reinterpret_cast<const u32x4*>(h->wf);
     fa.wf_last = reinterpret_cast<const u32x4*>(h->wf_last);
-    fa.bias_h = h->bias_h; fa.bias_last = h->bias_last;
     const double two_pi = 6.283185307179586476925286766559;
     fa.sc_first = (float)((double)h->cfg.first_omega_0 / two_pi);
     fa.sc_hidden = (float)((double)h->cfg.hidden_omega_0 / two_pi / (double)h->wscale);
@@ -287,60 +273,50 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
       if (rc) return rc;
     }
     if (!train) continue;
-    BwdArgs ba;
-    memset(&ba, 0, sizeof(ba));
-    ba.depth = D;
-    ba.wb = reinterpret_cast<const u32x4*>(h->wb);
-    ba.wb_last = reinterpret_cast<const u32x4*>(h->wb_last);
-    ba.P = h->Pbuf; ba.p_stride = h->p_stride; ba.Dlast = h->Dlast; ba.D = h->Dbuf;
-    ba.om_first = h->cfg.first_omega_0; ba.om_hidden = h->cfg.hidden_omega_0;
-    {
-      Launch L(h, K_BWDX, flops_bwdx_px(h) * n_pb * 32.0, n_pb * 32.0 * ((D - 1) * WD * 4.0 + 64.0));
-      rc = launch_bwdx(h, ba, n_super);
-      L.done();
-      if (rc) return rc;
-    }
-    // weight gradients, last layer first (autograd order is irrelevant: each layer has its own slab pass)
+    // backward, last layer first; every layer kernel is followed by the fixed-order slab reduction
     const int PBS = 2;
     int n_wg = (int)((n_pb + PBS - 1) / PBS);
     if (n_wg > h->dw_wg) n_wg = h->dw_wg;
     long pb_per_wg = (n_pb + n_wg - 1) / n_wg;
     pb_per_wg = (pb_per_wg + PBS - 1) / PBS * PBS;
     n_wg = (int)((n_pb + pb_per_wg - 1) / pb_per_wg);
+    const size_t img_pieces = (size_t)WD * WD / 8;
     for (int l = D - 1; l >= 0; --l) {
-      DwArgs da;
-      memset(&da, 0, sizeof(da));
-      da.gh = h->gh; da.gw = h->gw; da.W = h->cfg.width; da.row_begin = h->cfg.row_begin;
-      da.pix0 = pix0; da.npix = h->npix; da.n_pb = n_pb; da.pb_per_wg = (int)pb_per_wg; da.slab = h->slab;
       ReduceArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.slab = h->slab; ra.n_wg = n_wg; ra.accumulate = c > 0;
       ra.gW = h->grads + h->off_w[l]; ra.gb = h->grads + h->off_b[l];
-      int which, kid;
-      double fl, by;
-      if (l == D - 1) {
-        which = 1; kid = K_DW_LAST;
-        da.A = h->Dlast;
-        da.Bp = h->Pbuf + (size_t)(D - 2) * h->p_stride;
-        ra.slab_rows = 32; ra.slab_cols = WD; ra.rows_out = h->cfg.out_features; ra.cols_out = WD; ra.mode = 0;
-        fl = 2.0 * h->cfg.out_features * WD; by = 64.0 + WD * 2.0;
-      } else if (l == 0) {
-        which = 2; kid = K_DW_FIRST;
-        da.A = h->Dbuf;
-        ra.slab_rows = WD; ra.slab_cols = 32; ra.rows_out = WD; ra.cols_out = 2; ra.mode = 1;
-        fl = 2.0 * 2 * WD; by = WD * 2.0;
-      } else {
-        which = 0; kid = K_DW_HIDDEN;
-        da.A = h->Dbuf + (size_t)l * h->p_stride;
-        da.Bp = h->Pbuf + (size_t)(l - 1) * h->p_stride;
-        ra.slab_rows = WD; ra.slab_cols = WD; ra.rows_out = WD; ra.cols_out = WD; ra.mode = 0;
-        fl = 2.0 * WD * WD; by = WD * 4.0;
-      }
-      {
-        Launch L(h, kid, fl * n_pb * 32.0, by * n_pb * 32.0);
-        rc = launch_dw(h, which, da, n_wg);
+      if (l > 0) {
+        const bool last = l == D - 1;
+        BwdLayerArgs ba;
+        memset(&ba, 0, sizeof(ba));
+        ba.D = last ? h->Dlast : h->Dbuf + (size_t)l * h->p_stride;
+        ba.P = h->Pbuf + (size_t)(l - 1) * h->p_stride;
+        ba.Dout = h->Dbuf + (size_t)(l - 1) * h->p_stride;
+        ba.wb = last ? reinterpret_cast<const u32x4*>(h->wb_last)
+                     : reinterpret_cast<const u32x4*>(h->wb) + (size_t)(l - 1) * img_pieces;
+        ba.n_pb = n_pb; ba.pb_per_wg = (int)pb_per_wg;
+        ba.om = (l - 1 == 0) ? h->cfg.first_omega_0 : h->cfg.hidden_omega_0;
+        ba.slab = h->slab;
+        const double rows = last ? h->cfg.out_features : WD;
+        Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 4.0 * rows * WD * n_pb * 32.0,
+                 n_pb * 32.0 * ((last ? 64.0 : WD * 2.0) + WD * 4.0));
+        rc = launch_bwd(h, last, ba, n_wg);
         L.done();
         if (rc) return rc;
+        ra.slab_rows = last ? 32 : WD; ra.slab_cols = WD;
+        ra.rows_out = last ? h->cfg.out_features : WD; ra.cols_out = WD; ra.mode = 0;
+      } else {
+        DwArgs da;
+        memset(&da, 0, sizeof(da));
+        da.gh = h->gh; da.gw = h->gw; da.W = h->cfg.width; da.row_begin = h->cfg.row_begin;
+        da.pix0 = pix0; da.npix = h->npix; da.n_pb = n_pb; da.pb_per_wg = (int)pb_per_wg; da.slab = h->slab;
+        da.A = h->Dbuf;
+        Launch L(h, K_DW_FIRST, 4.0 * WD * n_pb * 32.0, WD * 2.0 * n_pb * 32.0);
+        rc = launch_dw_first(h, da, n_wg);
+        L.done();
+        if (rc) return rc;
+        ra.slab_rows = WD; ra.slab_cols = 32; ra.rows_out = WD; ra.cols_out = 2; ra.mode = 1;
       }
       {
         const int n = ra.rows_out * ra.cols_out + ra.rows_out;
@@ -423,7 +399,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   // fp16 forward images are scaled by 2^8 so that small weights stay normal numbers
   h->wscale = cfg->compute_dtype == SF_F16 ? 256.0f : 1.0f;
   // chunking
-  long chunk = cfg->chunk_pixels > 0 ? cfg->chunk_pixels : (1L << 20);
+  long chunk = cfg->chunk_pixels > 0 ? cfg->chunk_pixels : (1L << 22);
   chunk = (chunk + kSuper - 1) / kSuper * kSuper;
   const long npix_pad = (h->npix + kSuper - 1) / kSuper * kSuper;
   if (chunk > npix_pad) chunk = npix_pad;
@@ -442,9 +418,9 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   ALLOC(h->params, h->P * 4); ALLOC(h->grads, h->P * 4); ALLOC(h->m, h->P * 4); ALLOC(h->v, h->P * 4);
   ALLOC(h->mask, h->P * 4);
   const size_t img_elems = (size_t)(D - 2 > 0 ? D - 2 : 1) * WD * WD;
-  ALLOC(h->wf, img_elems * 2); ALLOC(h->wb, img_elems * 2);
-  ALLOC(h->wf_last, (size_t)WD / 16 * 64 * 16); ALLOC(h->wb_last, (size_t)WD / 32 * 64 * 16);
-  ALLOC(h->l0tab, (size_t)WD * 16); ALLOC(h->bias_h, img_elems / WD * 4); ALLOC(h->bias_last, 32 * 4);
+  ALLOC(h->wf, (size_t)(D - 2 > 0 ? D - 2 : 1) * FwdGeom(WD).PIECES * 1024); ALLOC(h->wb, img_elems * 2);
+  ALLOC(h->wf_last, (size_t)(WD / 16 + 1) * 1024); ALLOC(h->wb_last, (size_t)WD / 32 * 64 * 16);
+  ALLOC(h->l0tab, (size_t)WD * 16);
   ALLOC(h->gh, (size_t)cfg->height * 4); ALLOC(h->gw, (size_t)cfg->width * 4);
   ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->p_stride * 16);
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
@@ -466,7 +442,7 @@ int sf_destroy(sf_handle* h) {
   if (h->stream || true) hipStreamSynchronize(h->stream);
   for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab,
-                  h->bias_h, h->bias_last, h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part,
+                  h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part,
                   h->sse_dev};
   for (void* p : ptrs) if (p) hipFree(p);
   delete h;

@@ -64,6 +64,24 @@ DEV float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u
 
 constexpr float kInv65535 = 1.0f / 65535.0f;
 
+// workgroup barriers that do NOT drain in-flight global_load_lds (a plain __syncthreads() would)
+DEV void bar_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+DEV void bar_all() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+DEV void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // k_fwd
 // ---------------------------------------------------------------------------------------------
@@ -76,10 +94,8 @@ struct FwdArgs {
   long npix;               // local pixels of the handle (valid: pix < npix)
   int depth;               // number of Linear layers
   const f32x4* l0tab;      // [WD] {w00, w01, b0, 0}
-  const u32x4* wf;         // (depth-2) forward images, WD*WD/8 pieces each
-  const u32x4* wf_last;    // forward image of the last layer padded to 32 rows: WD/16 * 64 pieces
-  const float* bias_h;     // (depth-2) x WD, pre-multiplied by the weight-image scale
-  const float* bias_last;  // [32], pre-multiplied by the weight-image scale, rows >= out_features zero
+  const u32x4* wf;         // (depth-2) forward images (FwdImg<WD>::PIECES pieces each, biases included)
+  const u32x4* wf_last;    // forward image of the last layer padded to 32 rows + bias piece
   float sc_first;          // first_omega_0 / (2 pi)
   float sc_hidden;         // hidden_omega_0 / (2 pi) / weight-image scale
   float sc_last;           // 1 / weight-image scale
@@ -92,19 +108,40 @@ struct FwdArgs {
   float* sse_part;         // [gridDim.x] per-workgroup sum of squared residuals
 };
 
+// Forward weight image of one hidden layer, as stored in HBM and copied verbatim into LDS:
+//   [half 0: tiles 0..H0-1, KS pieces each][bias piece 0][half 1: tiles H0..NT-1][bias piece 1]
+// (piece = 1 KiB = 64 lanes x 16 B; a bias piece holds the 32*tiles fp32 biases of its half, pre-scaled).
+// The two halves are the double-buffering unit of k_fwd: while the waves run the MFMAs of one half, the
+// other half of the NEXT layer is in flight (global_load_lds).
+template <int WD>
+struct FwdImg {
+  static constexpr int NT = WD / 32, KS = WD / 16;
+  static constexpr int H0 = NT >= 2 ? NT / 2 : 1, H1 = NT - H0;
+  static constexpr int X_PIECES = H0 * KS + 1, Y_PIECES = H1 * KS + 1;
+  static constexpr int PIECES = X_PIECES + Y_PIECES;            // per hidden layer
+  static constexpr int LAST_PIECES = KS + 1;                     // last layer: one 32-row tile + bias piece
+  static __host__ __device__ constexpr int tile_piece(int nt) { return nt < H0 ? nt * KS : X_PIECES + (nt - H0) * KS; }
+  static __host__ __device__ constexpr int bias_piece(int nt) { return nt < H0 ? H0 * KS : X_PIECES + H1 * KS; }
+  static __host__ __device__ constexpr int bias_off(int nt) { return (nt < H0 ? nt : nt - H0) * 32; }
+};
+
 template <int WD, typename OP, bool TRAIN>
 __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
-  constexpr int NT = WD / 32, KS = WD / 16;
+  using IM = FwdImg<WD>;
+  constexpr int NT = IM::NT, KS = IM::KS, H0 = IM::H0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  u32x4* sW = reinterpret_cast<u32x4*>(smem);                               // NT*KS*64 pieces
-  f32x4* sL0 = reinterpret_cast<f32x4*>(smem + (size_t)NT * KS * 1024);     // WD
-  float* sBias = reinterpret_cast<float*>(sL0 + WD);                        // WD (>= 32)
-  float* sRed = sBias + (WD < 32 ? 32 : WD);                                // 8
+  u32x4* sW = reinterpret_cast<u32x4*>(smem);                                  // IM::PIECES pieces
+  f32x4* sL0 = reinterpret_cast<f32x4*>(smem + (size_t)IM::PIECES * 1024);     // WD
+  float* sRed = reinterpret_cast<float*>(sL0 + WD);                            // 8
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // async copy of `n` image pieces (1 KiB each) into LDS pieces [dst, dst+n), spread over the 8 waves
+  auto stage = [&](const u32x4* src, int dst, int n) {
+    for (int pc = wave; pc < n; pc += kWavesFwd) glds16(src + pc * 64 + lane, smem + (size_t)(dst + pc) * 1024);
+  };
   for (int i = tid; i < WD; i += 512) sL0[i] = a.l0tab[i];
-  __syncthreads();
-
   const long pb = (long)blockIdx.x * kWavesFwd + wave;  // pixel block inside the chunk
   const long pix = a.pix0 + pb * 32 + m;
   const bool valid = pix < a.npix;
@@ -112,6 +149,17 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   const int row = (int)(pc / a.W), col = (int)(pc - (long)row * a.W);
   const float x0 = (a.gh[a.row_begin + row] - 0.5f) * 2.0f;  // siren.py:128
   const float x1 = (a.gw[col] - 0.5f) * 2.0f;
+  float tgt[3] = {0.f, 0.f, 0.f};
+  if (a.img && h == 0 && valid) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tgt[c] = a.img[pix * 3 + c];
+  }
+  // the ordinary loads above are consumed before the first DMA is issued, so the compiler's
+  // vmcnt(0) for them does not drain the weight prefetch
+  asm volatile("" :: "v"(x0), "v"(x1), "v"(tgt[0]), "v"(tgt[1]), "v"(tgt[2]));
+  if (a.depth > 2) stage(a.wf, 0, IM::X_PIECES);
+  else stage(a.wf_last, 0, IM::LAST_PIECES);
+  bar_lds();   // layer-0 table visible (does not wait for the weight DMA)
 
   u32x4 B[KS];
   // ---- layer 0: K = 2, f32 VALU, written straight into B-fragment order -----------------------
@@ -132,58 +180,63 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
                                              pack_phase2(ph[4], ph[5]), pack_phase2(ph[6], ph[7])};
   }
 
+  // one 32-neuron output tile: bias-initialised accumulator, KS MFMAs, sine epilogue
+  auto tile = [&](int nt, int l, u32x4* Bn) {
+    f32x16 acc;
+    const float* bias = reinterpret_cast<const float*>(sW + IM::bias_piece(nt) * 64) + IM::bias_off(nt);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&bias[8 * q4 + 4 * h]);
+      acc[4 * q4 + 0] = b.x; acc[4 * q4 + 1] = b.y; acc[4 * q4 + 2] = b.z; acc[4 * q4 + 3] = b.w;
+    }
+    const u32x4* wt = sW + IM::tile_piece(nt) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = OP::mfma(wt[s * 64], B[s], acc);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float av[8], ph[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float tt = acc[8 * q + j] * a.sc_hidden;
+        av[j] = __builtin_amdgcn_sinf(tt);
+        ph[j] = __builtin_amdgcn_fractf(tt);
+      }
+      Bn[2 * nt + q] =
+          u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]), OP::pack2(av[6], av[7])};
+      if (TRAIN)
+        a.P[(size_t)l * a.p_stride + (pb * KS + 2 * nt + q) * 64 + lane] =
+            u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
+                  pack_phase2(ph[6], ph[7])};
+    }
+  };
+
   // ---- hidden layers: [WD x WD] on MFMA, activations stay in registers ------------------------
   for (int l = 1; l <= a.depth - 2; ++l) {
-    __syncthreads();
-    {
-      const u32x4* src = a.wf + (size_t)(l - 1) * NT * KS * 64;
-#pragma unroll
-      for (int i = tid; i < NT * KS * 64; i += 512) sW[i] = src[i];
-      if (tid < WD) sBias[tid] = a.bias_h[(l - 1) * WD + tid];
-    }
-    __syncthreads();
+    const u32x4* img_l = a.wf + (size_t)(l - 1) * IM::PIECES * 64;
     u32x4 Bn[KS];
+    bar_all();                                    // half X of layer l landed; everyone left half Y of layer l-1
+    stage(img_l + IM::X_PIECES * 64, IM::X_PIECES, IM::Y_PIECES);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x16 acc;
+    for (int nt = 0; nt < H0; ++nt) tile(nt, l, Bn);
+    bar_all();                                    // half Y landed; everyone left half X
+    if (l < a.depth - 2) stage(img_l + IM::PIECES * 64, 0, IM::X_PIECES);
+    else stage(a.wf_last, 0, IM::LAST_PIECES);
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&sBias[32 * nt + 8 * q4 + 4 * h]);
-        acc[4 * q4 + 0] = b.x; acc[4 * q4 + 1] = b.y; acc[4 * q4 + 2] = b.z; acc[4 * q4 + 3] = b.w;
-      }
-#pragma unroll
-      for (int s = 0; s < KS; ++s) acc = OP::mfma(sW[(nt * KS + s) * 64 + lane], B[s], acc);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float av[8], ph[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float tt = acc[8 * q + j] * a.sc_hidden;
-          av[j] = __builtin_amdgcn_sinf(tt);
-          ph[j] = __builtin_amdgcn_fractf(tt);
-        }
-        Bn[2 * nt + q] =
-            u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]), OP::pack2(av[6], av[7])};
-        if (TRAIN)
-          a.P[(size_t)l * a.p_stride + (pb * KS + 2 * nt + q) * 64 + lane] =
-              u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
-                    pack_phase2(ph[6], ph[7])};
-      }
-    }
+    for (int nt = H0; nt < NT; ++nt) tile(nt, l, Bn);
 #pragma unroll
     for (int s = 0; s < KS; ++s) B[s] = Bn[s];
   }
 
   // ---- last layer (out_features <= 3, padded to one 32-row tile) + residual ---------------------
-  __syncthreads();
-  for (int i = tid; i < KS * 64; i += 512) sW[i] = a.wf_last[i];
-  if (tid < 32) sBias[tid] = a.bias_last[tid];
-  __syncthreads();
+  bar_all();
   f32x16 acc;
+  {
+    const float* bias = reinterpret_cast<const float*>(sW + KS * 64);
 #pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(&sBias[8 * q4 + 4 * h]);
-    acc[4 * q4 + 0] = b.x; acc[4 * q4 + 1] = b.y; acc[4 * q4 + 2] = b.z; acc[4 * q4 + 3] = b.w;
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&bias[8 * q4 + 4 * h]);
+      acc[4 * q4 + 0] = b.x; acc[4 * q4 + 1] = b.y; acc[4 * q4 + 2] = b.z; acc[4 * q4 + 3] = b.w;
+    }
   }
 #pragma unroll
   for (int s = 0; s < KS; ++s) acc = OP::mfma(sW[s * 64 + lane], B[s], acc);
@@ -196,7 +249,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
       const float p = acc[c] * a.sc_last * 0.5f + 0.5f;  // siren.py:131
       if (a.pred) a.pred[pix * 3 + c] = p;
       if (a.img) {
-        const float r = p - a.img[pix * 3 + c];
+        const float r = p - tgt[c];
         sse += r * r;
         d[c] = r * a.gscale;
       }
@@ -216,96 +269,6 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
     float t = 0.f;
     for (int w = 0; w < kWavesFwd; ++w) t += sRed[w];
     a.sse_part[blockIdx.x] = t;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_bwdx: delta chain.  delta_l = dL/dz_l (z = pre-activation).  delta_{l-1} = (delta_l W_l) * omega cos(omega z_{l-1})
-// ---------------------------------------------------------------------------------------------
-struct BwdArgs {
-  int depth;
-  const u32x4* wb;        // backward images of layers 1..depth-2 (WD*WD/8 pieces each), bf16
-  const u32x4* wb_last;   // backward image of the last layer: NT tiles x 1 k-step x 64 pieces
-  const u32x4* P;         // phases
-  long p_stride;
-  const u32x4* Dlast;     // F-layout, 2 k-steps
-  u32x4* D;               // deltas of layers 0..depth-2, layer l at D + l*p_stride, F-layout bf16
-  float om_first, om_hidden;  // radians: d sin(om z)/dz = om cos(om z)
-};
-
-template <int WD>
-__global__ __launch_bounds__(512) void k_bwdx(BwdArgs a) {
-  constexpr int NT = WD / 32, KS = WD / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  u32x4* sW = reinterpret_cast<u32x4*>(smem);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const long pb = (long)blockIdx.x * kWavesFwd + wave;
-
-  u32x4 B[KS];
-  // ---- through the last layer: G = delta_last * W_last (one k-step, padded) ---------------------
-  for (int i = tid; i < NT * 64; i += 512) sW[i] = a.wb_last[i];
-  __syncthreads();
-  {
-    const u32x4 b0 = a.Dlast[(pb * 2) * 64 + lane];
-    const int l = a.depth - 2;  // producing delta of layer depth-2
-    const float om = (l == 0) ? a.om_first : a.om_hidden;
-#pragma unroll
-    for (int it = 0; it < NT; ++it) {
-      f32x16 acc = {};
-      acc = OpBF16::mfma(sW[it * 64 + lane], b0, acc);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const u32x4 p = a.P[(size_t)l * a.p_stride + (pb * KS + 2 * it + q) * 64 + lane];
-        float dv[8];
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) {
-          const float c0 = __builtin_amdgcn_cosf((float)(p[j2] & 0xffffu) * kInv65535);
-          const float c1 = __builtin_amdgcn_cosf((float)(p[j2] >> 16) * kInv65535);
-          dv[2 * j2] = acc[8 * q + 2 * j2] * (om * c0);
-          dv[2 * j2 + 1] = acc[8 * q + 2 * j2 + 1] * (om * c1);
-        }
-        const u32x4 o = u32x4{OpBF16::pack2(dv[0], dv[1]), OpBF16::pack2(dv[2], dv[3]), OpBF16::pack2(dv[4], dv[5]),
-                              OpBF16::pack2(dv[6], dv[7])};
-        B[2 * it + q] = o;
-        a.D[(size_t)l * a.p_stride + (pb * KS + 2 * it + q) * 64 + lane] = o;
-      }
-    }
-  }
-  // ---- hidden layers, from depth-2 down to 1: produces delta_{l-1} ------------------------------
-  for (int l = a.depth - 2; l >= 1; --l) {
-    __syncthreads();
-    {
-      const u32x4* src = a.wb + (size_t)(l - 1) * NT * KS * 64;
-#pragma unroll
-      for (int i = tid; i < NT * KS * 64; i += 512) sW[i] = src[i];
-    }
-    __syncthreads();
-    const float om = (l - 1 == 0) ? a.om_first : a.om_hidden;
-    u32x4 Bn[KS];
-#pragma unroll
-    for (int it = 0; it < NT; ++it) {
-      f32x16 acc = {};
-#pragma unroll
-      for (int s = 0; s < KS; ++s) acc = OpBF16::mfma(sW[(it * KS + s) * 64 + lane], B[s], acc);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const u32x4 p = a.P[(size_t)(l - 1) * a.p_stride + (pb * KS + 2 * it + q) * 64 + lane];
-        float dv[8];
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) {
-          const float c0 = __builtin_amdgcn_cosf((float)(p[j2] & 0xffffu) * kInv65535);
-          const float c1 = __builtin_amdgcn_cosf((float)(p[j2] >> 16) * kInv65535);
-          dv[2 * j2] = acc[8 * q + 2 * j2] * (om * c0);
-          dv[2 * j2 + 1] = acc[8 * q + 2 * j2 + 1] * (om * c1);
-        }
-        const u32x4 o = u32x4{OpBF16::pack2(dv[0], dv[1]), OpBF16::pack2(dv[2], dv[3]), OpBF16::pack2(dv[4], dv[5]),
-                              OpBF16::pack2(dv[6], dv[7])};
-        Bn[2 * it + q] = o;
-        a.D[(size_t)(l - 1) * a.p_stride + (pb * KS + 2 * it + q) * 64 + lane] = o;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) B[s] = Bn[s];
   }
 }
 
@@ -469,6 +432,172 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_dw(DwArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_bwd: one layer of the backward pass, data-gradient and weight-gradient fused so that every
+// scratch tensor is read exactly once:
+//     reads   D_l     (delta of layer l, rows j)          F-layout bf16
+//             P_{l-1} (phase of layer l-1, cols i)        F-layout unorm16
+//     writes  D_{l-1} = (D_l W_l) * omega cos(P_{l-1})     F-layout bf16
+//     accumulates dW_l[j][i] += D_l^T sin(P_{l-1}),  db_l[j] += sum D_l    (per-workgroup slab)
+//   Per 64-pixel tile (double-buffered in LDS by global_load_lds):
+//     phase X: wave w keeps rows [32w,32w+32) of W_l^T in registers (stationary A operand); B = delta
+//              pieces read lane-linear from LDS; epilogue reads the raw phase piece it owns, forms
+//              cos (for delta_{l-1}, stored to HBM) and sin (bf16, written back IN PLACE over the phase);
+//     phase W: dW MFMAs with both operands read transposed (ds_read_b64_tr_b16) from the two LDS images.
+// ---------------------------------------------------------------------------------------------
+struct BwdLayerArgs {
+  const u32x4* D;       // delta image of layer l (JW/16 k-steps per pixel block)
+  const u32x4* P;       // phase image of layer l-1 (IW/16 k-steps per pixel block)
+  u32x4* Dout;          // delta image of layer l-1
+  const u32x4* wb;      // backward weight image of layer l: tiles (IW/32) x k-steps (KSX) x 64 lanes
+  long n_pb;            // pixel blocks in this chunk
+  int pb_per_wg;        // multiple of 2
+  float om;             // omega of layer l-1 (radians)
+  float* slab;          // [gridDim.x][JW*IW + JW]
+};
+
+template <int JW, int IW, int WAVES_R, int WAVES_C, bool LAST>
+__global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
+  constexpr int NW = WAVES_R * WAVES_C;
+  constexpr int JT = JW / 32, IT = IW / 32;
+  constexpr int WJ = JT / WAVES_R, WI = IT / WAVES_C;
+  constexpr int KSJ = JW / 16, KSI = IW / 16;
+  constexpr int KSX = LAST ? 1 : KSJ;         // k-steps of the dX product (last layer: <= 3 real rows -> one step)
+  constexpr int PBS = 2;                      // pixel blocks per tile
+  // phase-X work split: IT row tiles x PBS pixel blocks over NW waves
+  constexpr int XT = IT >= NW ? IT / NW : 1;  // row tiles per wave
+  constexpr int NG = IT >= NW ? 1 : NW / IT;  // pixel-block groups when there are more waves than row tiles
+  static_assert((IT >= NW ? IT % NW == 0 : NW % IT == 0) && PBS % NG == 0, "phase-X tiling");
+  constexpr int BUF = PBS * (KSJ + KSI) * 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WAVES_C, wc = wave % WAVES_C;
+  const int xit0 = IT >= NW ? wave * XT : wave % IT, xg = IT >= NW ? 0 : wave / IT;
+
+  // stationary W^T rows of this wave
+  u32x4 wreg[XT][KSX];
+#pragma unroll
+  for (int x = 0; x < XT; ++x)
+#pragma unroll
+    for (int s = 0; s < KSX; ++s) wreg[x][s] = a.wb[((xit0 + x) * KSX + s) * 64 + lane];
+
+  f32x16 acc[WJ][WI];
+#pragma unroll
+  for (int x = 0; x < WJ; ++x)
+#pragma unroll
+    for (int y = 0; y < WI; ++y) acc[x][y] = f32x16{};
+  float dbs[WJ];
+#pragma unroll
+  for (int x = 0; x < WJ; ++x) dbs[x] = 0.f;
+
+  const long pb_begin = (long)blockIdx.x * a.pb_per_wg;
+  long pb_end = pb_begin + a.pb_per_wg;
+  if (pb_end > a.n_pb) pb_end = a.n_pb;
+  const int n_tiles = (int)((pb_end - pb_begin) / PBS);
+
+  auto stage = [&](int buf, long pb) {
+    char* base = smem + buf * BUF;
+    // D pieces then P pieces, one 1 KiB piece per wave-instruction
+    for (int pc = wave; pc < PBS * KSJ; pc += NW)
+      glds16(a.D + (pb * KSJ + pc) * 64 + lane, base + pc * 1024);
+    for (int pc = wave; pc < PBS * KSI; pc += NW)
+      glds16(a.P + (pb * KSI + pc) * 64 + lane, base + PBS * KSJ * 1024 + pc * 1024);
+  };
+
+  if (n_tiles > 0) stage(0, pb_begin);
+  for (int t = 0; t < n_tiles; ++t) {
+    const long pb = pb_begin + (long)t * PBS;
+    const int cur = t & 1;
+    bar_all();                                     // tile t landed; everyone finished tile t-1
+    if (t + 1 < n_tiles) stage(cur ^ 1, pb + PBS);
+    char* sD = smem + cur * BUF;
+    char* sP = sD + PBS * KSJ * 1024;
+    // ---------------- phase X: delta_{l-1} for this wave's row tiles ----------------
+#pragma unroll
+    for (int bi = xg; bi < PBS; bi += NG) {
+      f32x16 g[XT];
+#pragma unroll
+      for (int x = 0; x < XT; ++x) g[x] = f32x16{};
+#pragma unroll
+      for (int s = 0; s < KSX; ++s) {
+        const u32x4 b = reinterpret_cast<const u32x4*>(sD + (bi * KSJ + s) * 1024)[lane];
+#pragma unroll
+        for (int x = 0; x < XT; ++x) g[x] = OpBF16::mfma(wreg[x][s], b, g[x]);
+      }
+#pragma unroll
+      for (int x = 0; x < XT; ++x) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int ks = 2 * (xit0 + x) + q;
+          u32x4* pp = reinterpret_cast<u32x4*>(sP + (bi * KSI + ks) * 1024) + lane;
+          const u32x4 p = *pp;
+          float dv[8], sv[8];
+#pragma unroll
+          for (int j2 = 0; j2 < 4; ++j2) {
+            const float r0 = (float)(p[j2] & 0xffffu) * kInv65535, r1 = (float)(p[j2] >> 16) * kInv65535;
+            dv[2 * j2] = g[x][8 * q + 2 * j2] * (a.om * __builtin_amdgcn_cosf(r0));
+            dv[2 * j2 + 1] = g[x][8 * q + 2 * j2 + 1] * (a.om * __builtin_amdgcn_cosf(r1));
+            sv[2 * j2] = __builtin_amdgcn_sinf(r0);
+            sv[2 * j2 + 1] = __builtin_amdgcn_sinf(r1);
+          }
+          a.Dout[((pb + bi) * KSI + ks) * 64 + lane] =
+              u32x4{OpBF16::pack2(dv[0], dv[1]), OpBF16::pack2(dv[2], dv[3]), OpBF16::pack2(dv[4], dv[5]),
+                    OpBF16::pack2(dv[6], dv[7])};
+          *pp = u32x4{OpBF16::pack2(sv[0], sv[1]), OpBF16::pack2(sv[2], sv[3]), OpBF16::pack2(sv[4], sv[5]),
+                      OpBF16::pack2(sv[6], sv[7])};
+        }
+      }
+    }
+    bar_lds();                                     // activations in place (keeps tile t+1's DMA in flight)
+    // ---------------- phase W: dW += delta^T * act ----------------
+#pragma unroll
+    for (int bi = 0; bi < PBS; ++bi) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        u32x4 fa[WJ], fb[WI];
+#pragma unroll
+        for (int x = 0; x < WJ; ++x)
+          fa[x] = ds_read_tr_pair(sD + bi * KSJ * 1024, tr_addr(wr * WJ + x, kk, 0, lane),
+                                  tr_addr(wr * WJ + x, kk, 1, lane));
+#pragma unroll
+        for (int y = 0; y < WI; ++y)
+          fb[y] = ds_read_tr_pair(sP + bi * KSI * 1024, tr_addr(wc * WI + y, kk, 0, lane),
+                                  tr_addr(wc * WI + y, kk, 1, lane));
+#pragma unroll
+        for (int x = 0; x < WJ; ++x)
+#pragma unroll
+          for (int y = 0; y < WI; ++y) acc[x][y] = OpBF16::mfma(fa[x], fb[y], acc[x][y]);
+        if (wc == 0) {
+#pragma unroll
+          for (int x = 0; x < WJ; ++x) {
+            float tsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tsum += bf16_lo(fa[x][e]) + bf16_hi(fa[x][e]);
+            dbs[x] += tsum;
+          }
+        }
+      }
+    }
+  }
+  float* slab = a.slab + (size_t)blockIdx.x * (JW * IW + JW);
+  const int cl = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int x = 0; x < WJ; ++x)
+#pragma unroll
+    for (int y = 0; y < WI; ++y)
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        slab[(size_t)(32 * (wr * WJ + x) + rho(t, hh)) * IW + 32 * (wc * WI + y) + cl] = acc[x][y][t];
+  if (wc == 0) {
+#pragma unroll
+    for (int x = 0; x < WJ; ++x) {
+      const float tsum = dbs[x] + __shfl_xor(dbs[x], 32);
+      if (hh == 0) slab[JW * IW + 32 * (wr * WJ + x) + cl] = tsum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_reduce: flat gradient from the slabs, fixed summation order (workgroup 0, 1, 2, ...).
 //   mode 0: hidden / last layer: gW[j][i] = sum slab[j][i] (j < rows_out, i < cols_out), gb[j] = sum db[j]
 //   mode 1: first layer: gW[j][0] = c0+c1, gW[j][1] = c2+c3 ; gb[j] = db[j]
@@ -554,13 +683,25 @@ struct ImgArgs {
   float wscale;             // forward-image scale (power of two)
   int fwd_is_f16;
   uint16_t* wf; uint16_t* wf_last; uint16_t* wb; uint16_t* wb_last;
-  f32x4* l0tab; float* bias_h; float* bias_last;
+  f32x4* l0tab;
 };
 DEV uint16_t to_bf16(float x) { return (uint16_t)(OpBF16::pack2(x, 0.f) & 0xffffu); }
 DEV uint16_t to_f16(float x) { return (uint16_t)(OpF16::pack2(x, 0.f) & 0xffffu); }
 
+// forward-image geometry for a run-time width (mirrors FwdImg<WD>)
+struct FwdGeom {
+  int NT, KS, H0, H1, XP, PIECES;
+  __host__ __device__ explicit FwdGeom(int WD) {
+    NT = WD / 32; KS = WD / 16; H0 = NT >= 2 ? NT / 2 : 1; H1 = NT - H0; XP = H0 * KS + 1; PIECES = XP + H1 * KS + 1;
+  }
+  __host__ __device__ int tile_piece(int nt) const { return nt < H0 ? nt * KS : XP + (nt - H0) * KS; }
+  __host__ __device__ int bias_piece(int nt) const { return nt < H0 ? H0 * KS : XP + H1 * KS; }
+  __host__ __device__ int bias_off(int nt) const { return (nt < H0 ? nt : nt - H0) * 32; }
+};
+
 __global__ void k_images(ImgArgs a) {
   const int WD = a.WD, NT = WD / 32, KS = WD / 16;
+  const FwdGeom G(WD);
   const long per_layer = (long)WD * WD;
   const long n_hidden = (long)(a.depth - 2) * per_layer;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -575,8 +716,14 @@ __global__ void k_images(ImgArgs a) {
     const float* Wl = a.params + a.off_w[l];
     const float wfwd = Wl[(long)(32 * tile + r) * WD + 16 * s + pi_perm(h, j)] * a.wscale;
     const float wbwd = Wl[(long)(16 * s + pi_perm(h, j)) * WD + 32 * tile + r];
-    a.wf[gid] = a.fwd_is_f16 ? to_f16(wfwd) : to_bf16(wfwd);
+    const long dst = ((long)(l - 1) * G.PIECES + G.tile_piece(tile) + s) * 512 + lane * 8 + j;
+    a.wf[dst] = a.fwd_is_f16 ? to_f16(wfwd) : to_bf16(wfwd);
     a.wb[gid] = to_bf16(wbwd);
+  }
+  if (gid < (long)(a.depth - 2) * WD) {  // hidden biases into the bias pieces (fp32, pre-scaled)
+    const int l = (int)(gid / WD) + 1, n = (int)(gid % WD), nt = n / 32;
+    float* piece = reinterpret_cast<float*>(a.wf + ((long)(l - 1) * G.PIECES + G.bias_piece(nt)) * 512);
+    piece[G.bias_off(nt) + (n & 31)] = a.params[a.off_b[l] + n] * a.wscale;
   }
   const int L = a.depth - 1;
   if (gid < (long)KS * 64 * 8) {  // last layer forward image: one tile of 32 padded rows
@@ -588,6 +735,10 @@ __global__ void k_images(ImgArgs a) {
     float w = 0.f;
     if (r < a.out_features) w = a.params[a.off_w[L] + (long)r * WD + 16 * s + pi_perm(h, j)] * a.wscale;
     a.wf_last[gid] = a.fwd_is_f16 ? to_f16(w) : to_bf16(w);
+  }
+  if (gid < 32) {
+    float* piece = reinterpret_cast<float*>(a.wf_last + (long)KS * 512);
+    piece[gid] = (gid < a.out_features) ? a.params[a.off_b[L] + gid] * a.wscale : 0.f;
   }
   if (gid < (long)NT * 64 * 8) {  // last layer backward image: NT tiles x 1 k-step
     long e = gid;
@@ -604,11 +755,6 @@ __global__ void k_images(ImgArgs a) {
     const float* W0 = a.params + a.off_w[0];
     a.l0tab[gid] = f32x4{W0[gid * 2], W0[gid * 2 + 1], a.params[a.off_b[0] + gid], 0.f};
   }
-  if (gid < (long)(a.depth - 2) * WD) {
-    const int l = (int)(gid / WD) + 1, n = (int)(gid % WD);
-    a.bias_h[gid] = a.params[a.off_b[l] + n] * a.wscale;
-  }
-  if (gid < 32) a.bias_last[gid] = (gid < a.out_features) ? a.params[a.off_b[L] + gid] * a.wscale : 0.f;
 }
 
 }  // namespace sf
