@@ -157,7 +157,7 @@ int launch_dw_t(sf_engine* h, const DwArgs& a, int n_wg) {
 
 template <int JW, int IW, int WR, int WC, bool LAST>
 int launch_bwd_t(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
-  const size_t lds = (size_t)2 * 2 * (JW / 16 + IW / 16) * 1024;
+  const size_t lds = (size_t)4 * (JW / 16 + IW / 16) * 1024;
   int rc = set_lds(k_bwd<JW, IW, WR, WC, LAST>, lds);
   if (rc) return rc;
   hipLaunchKernelGGL((k_bwd<JW, IW, WR, WC, LAST>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
@@ -169,8 +169,8 @@ int launch_bwd_t(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
 int launch_bwd(sf_engine* h, bool last, const BwdLayerArgs& a, int n_wg) {
   switch (h->WD) {
     case 32: return last ? launch_bwd_t<32, 32, 1, 1, true>(h, a, n_wg) : launch_bwd_t<32, 32, 1, 1, false>(h, a, n_wg);
-    case 64: return last ? launch_bwd_t<32, 64, 1, 2, true>(h, a, n_wg) : launch_bwd_t<64, 64, 2, 2, false>(h, a, n_wg);
-    case 128: return last ? launch_bwd_t<32, 128, 1, 4, true>(h, a, n_wg) : launch_bwd_t<128, 128, 2, 4, false>(h, a, n_wg);
+    case 64: return last ? launch_bwd_t<32, 64, 1, 2, true>(h, a, n_wg) : launch_bwd_t<64, 64, 2, 1, false>(h, a, n_wg);
+    case 128: return last ? launch_bwd_t<32, 128, 1, 4, true>(h, a, n_wg) : launch_bwd_t<128, 128, 2, 2, false>(h, a, n_wg);
     case 256: return last ? launch_bwd_t<32, 256, 1, 8, true>(h, a, n_wg) : launch_bwd_t<256, 256, 2, 2, false>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
@@ -274,7 +274,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     }
     if (!train) continue;
     // backward, last layer first; every layer kernel is followed by the fixed-order slab reduction
-    const int PBS = 2;
+    const int PBS = 2;   // k_dw stages two pixel blocks at a time; k_bwd accepts any block count
     int n_wg = (int)((n_pb + PBS - 1) / PBS);
     if (n_wg > h->dw_wg) n_wg = h->dw_wg;
     long pb_per_wg = (n_pb + n_wg - 1) / n_wg;
@@ -321,7 +321,13 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
       {
         const int n = ra.rows_out * ra.cols_out + ra.rows_out;
         Launch L(h, K_REDUCE, 0, (double)n_wg * n * 4.0);
-        hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, h->stream, ra);
+        if (l > 0 && l < D - 1) {   // slab layout == flat gradient layout [W | b]
+          const int n4 = n / 4;
+          hipLaunchKernelGGL(k_reduce_vec, dim3((n4 + 31) / 32), dim3(256), 0, h->stream, (const float*)h->slab,
+                             n_wg, (long)n, n4, h->grads + h->off_w[l], (int)ra.accumulate);
+        } else {
+          hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, h->stream, ra);
+        }
         L.done();
         HIPCHK(hipGetLastError());
       }
@@ -405,7 +411,9 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   if (chunk > npix_pad) chunk = npix_pad;
   h->chunk_px = chunk;
   const int WD = h->WD, D = h->D;
-  h->p_stride = chunk / 32 * (WD / 16) * 64;
+  // layer stride of the scratch tensors, padded so that the three streams a kernel touches at once are
+  // not a power of two apart (HBM channel aliasing)
+  h->p_stride = chunk / 32 * (WD / 16) * 64 + 37 * 64;
   h->dw_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
   auto alloc = [&](void** p, size_t bytes) -> int {

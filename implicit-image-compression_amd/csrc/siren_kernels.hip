@@ -75,6 +75,14 @@ DEV void bar_all() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+// barrier that waits for this wave's LDS-DMA but leaves its N YOUNGEST vector-memory operations (the
+// epilogue stores issued AFTER the DMA) in flight: vmcnt counts loads, stores and LDS-DMA in issue order
+template <int N>
+DEV void bar_dma() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 
 DEV void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -159,6 +167,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   asm volatile("" :: "v"(x0), "v"(x1), "v"(tgt[0]), "v"(tgt[1]), "v"(tgt[2]));
   if (a.depth > 2) stage(a.wf, 0, IM::X_PIECES);
   else stage(a.wf_last, 0, IM::LAST_PIECES);
+  asm volatile("" ::: "memory");
   bar_lds();   // layer-0 table visible (does not wait for the weight DMA)
 
   u32x4 B[KS];
@@ -214,13 +223,17 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   for (int l = 1; l <= a.depth - 2; ++l) {
     const u32x4* img_l = a.wf + (size_t)(l - 1) * IM::PIECES * 64;
     u32x4 Bn[KS];
-    bar_all();                                    // half X of layer l landed; everyone left half Y of layer l-1
+    // half X of layer l landed (the stores of the previous half were issued after that DMA and may stay
+    // in flight); everyone left half Y of layer l-1
+    if (l == 1) bar_dma<TRAIN ? KS : 0>(); else bar_dma<TRAIN ? 2 * IM::H1 : 0>();
     stage(img_l + IM::X_PIECES * 64, IM::X_PIECES, IM::Y_PIECES);
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int nt = 0; nt < H0; ++nt) tile(nt, l, Bn);
-    bar_all();                                    // half Y landed; everyone left half X
+    bar_dma<TRAIN ? 2 * H0 : 0>();                // half Y landed; everyone left half X
     if (l < a.depth - 2) stage(img_l + IM::PIECES * 64, 0, IM::X_PIECES);
     else stage(a.wf_last, 0, IM::LAST_PIECES);
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int nt = H0; nt < NT; ++nt) tile(nt, l, Bn);
 #pragma unroll
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   }
 
   // ---- last layer (out_features <= 3, padded to one 32-row tile) + residual ---------------------
-  bar_all();
+  if (a.depth > 2) bar_dma<TRAIN ? 2 * IM::H1 : 0>(); else bar_dma<TRAIN ? KS : 0>();
   f32x16 acc;
   {
     const float* bias = reinterpret_cast<const float*>(sW + KS * 64);
@@ -438,8 +451,8 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_dw(DwArgs a) {
 //             P_{l-1} (phase of layer l-1, cols i)        F-layout unorm16
 //     writes  D_{l-1} = (D_l W_l) * omega cos(P_{l-1})     F-layout bf16
 //     accumulates dW_l[j][i] += D_l^T sin(P_{l-1}),  db_l[j] += sum D_l    (per-workgroup slab)
-//   Per 64-pixel tile (double-buffered in LDS by global_load_lds):
-//     phase X: wave w keeps rows [32w,32w+32) of W_l^T in registers (stationary A operand); B = delta
+//   32-pixel blocks stream through a 4-slot LDS ring filled by global_load_lds two blocks ahead:
+//     phase X: each wave keeps its rows of W_l^T in registers (stationary A operand); B = delta
 //              pieces read lane-linear from LDS; epilogue reads the raw phase piece it owns, forms
 //              cos (for delta_{l-1}, stored to HBM) and sin (bf16, written back IN PLACE over the phase);
 //     phase W: dW MFMAs with both operands read transposed (ds_read_b64_tr_b16) from the two LDS images.
@@ -462,17 +475,17 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   constexpr int WJ = JT / WAVES_R, WI = IT / WAVES_C;
   constexpr int KSJ = JW / 16, KSI = IW / 16;
   constexpr int KSX = LAST ? 1 : KSJ;         // k-steps of the dX product (last layer: <= 3 real rows -> one step)
-  constexpr int PBS = 2;                      // pixel blocks per tile
-  // phase-X work split: IT row tiles x PBS pixel blocks over NW waves
-  constexpr int XT = IT >= NW ? IT / NW : 1;  // row tiles per wave
-  constexpr int NG = IT >= NW ? 1 : NW / IT;  // pixel-block groups when there are more waves than row tiles
-  static_assert((IT >= NW ? IT % NW == 0 : NW % IT == 0) && PBS % NG == 0, "phase-X tiling");
-  constexpr int BUF = PBS * (KSJ + KSI) * 1024;
+  constexpr int XT = IT / NW;                 // phase-X row tiles per wave
+  static_assert(IT % NW == 0, "phase-X tiling needs NW <= IT");
+  constexpr int NB = 4;                       // LDS ring: blocks of 32 pixels
+  constexpr int BLK = (KSJ + KSI) * 1024;     // bytes per ring slot: delta pieces then phase pieces
+  constexpr int G_MIN = KSJ / NW + KSI / NW;  // LDS-DMA instructions every wave issues per block (lower bound)
+  constexpr int S_ST = 2 * XT;                // delta stores per wave per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WAVES_C, wc = wave % WAVES_C;
-  const int xit0 = IT >= NW ? wave * XT : wave % IT, xg = IT >= NW ? 0 : wave / IT;
+  const int xit0 = wave * XT;
 
   // stationary W^T rows of this wave
   u32x4 wreg[XT][KSX];
@@ -490,94 +503,105 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
 #pragma unroll
   for (int x = 0; x < WJ; ++x) dbs[x] = 0.f;
 
-  const long pb_begin = (long)blockIdx.x * a.pb_per_wg;
-  long pb_end = pb_begin + a.pb_per_wg;
-  if (pb_end > a.n_pb) pb_end = a.n_pb;
-  const int n_tiles = (int)((pb_end - pb_begin) / PBS);
+  // block-cyclic assignment: at any moment the workgroups stream NEIGHBOURING 16 KiB pieces of each tensor
+  // (contiguous ranges per workgroup would put all of them a power-of-two stride apart)
+  const long pb_begin = blockIdx.x, pb_step = gridDim.x;
+  const int nblk = (int)((a.n_pb - pb_begin + pb_step - 1) / pb_step);
 
-  auto stage = [&](int buf, long pb) {
-    char* base = smem + buf * BUF;
-    // D pieces then P pieces, one 1 KiB piece per wave-instruction
-    for (int pc = wave; pc < PBS * KSJ; pc += NW)
-      glds16(a.D + (pb * KSJ + pc) * 64 + lane, base + pc * 1024);
-    for (int pc = wave; pc < PBS * KSI; pc += NW)
-      glds16(a.P + (pb * KSI + pc) * 64 + lane, base + PBS * KSJ * 1024 + pc * 1024);
+  auto stage = [&](int k) {   // block k of this workgroup -> ring slot k % NB, one 1 KiB piece per wave-instruction
+    char* base = smem + (k & (NB - 1)) * BLK;
+    const long pb = pb_begin + k * pb_step;
+    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * KSJ + pc) * 64 + lane, base + pc * 1024);
+    for (int pc = wave; pc < KSI; pc += NW) glds16(a.P + (pb * KSI + pc) * 64 + lane, base + (KSJ + pc) * 1024);
   };
 
-  if (n_tiles > 0) stage(0, pb_begin);
-  for (int t = 0; t < n_tiles; ++t) {
-    const long pb = pb_begin + (long)t * PBS;
-    const int cur = t & 1;
-    bar_all();                                     // tile t landed; everyone finished tile t-1
-    if (t + 1 < n_tiles) stage(cur ^ 1, pb + PBS);
-    char* sD = smem + cur * BUF;
-    char* sP = sD + PBS * KSJ * 1024;
-    // ---------------- phase X: delta_{l-1} for this wave's row tiles ----------------
+  if (nblk > 0) stage(0);
+  if (nblk > 1) stage(1);
+  // Software pipeline over 32-pixel blocks; step k runs phase X on block k and phase W on block k-1 in
+  // one instruction stream (independent work: the VALU-heavy X epilogue hides under the W MFMAs).
+  //   X(k): delta_{k} B-pieces * stationary W^T -> G; epilogue: cos/sin of the phase piece this wave owns,
+  //         delta_{l-1} to HBM, sin (bf16) written back IN PLACE over the phase piece
+  //   W(k-1): dW += delta^T * act, both operands read transposed (ds_read_b64_tr_b16)
+  auto phase_x = [&](int k) {
+    char* sD = smem + (k & (NB - 1)) * BLK;
+    char* sP = sD + KSJ * 1024;
+    f32x16 g[XT];
 #pragma unroll
-    for (int bi = xg; bi < PBS; bi += NG) {
-      f32x16 g[XT];
+    for (int x = 0; x < XT; ++x) g[x] = f32x16{};
 #pragma unroll
-      for (int x = 0; x < XT; ++x) g[x] = f32x16{};
+    for (int s = 0; s < KSX; ++s) {
+      const u32x4 b = reinterpret_cast<const u32x4*>(sD + s * 1024)[lane];
 #pragma unroll
-      for (int s = 0; s < KSX; ++s) {
-        const u32x4 b = reinterpret_cast<const u32x4*>(sD + (bi * KSJ + s) * 1024)[lane];
+      for (int x = 0; x < XT; ++x) g[x] = OpBF16::mfma(wreg[x][s], b, g[x]);
+    }
 #pragma unroll
-        for (int x = 0; x < XT; ++x) g[x] = OpBF16::mfma(wreg[x][s], b, g[x]);
+    for (int x = 0; x < XT; ++x) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ks = 2 * (xit0 + x) + q;
+        u32x4* pp = reinterpret_cast<u32x4*>(sP + ks * 1024) + lane;
+        const u32x4 p = *pp;
+        float dv[8], sv[8];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          const float r0 = (float)(p[j2] & 0xffffu) * kInv65535, r1 = (float)(p[j2] >> 16) * kInv65535;
+          dv[2 * j2] = g[x][8 * q + 2 * j2] * (a.om * __builtin_amdgcn_cosf(r0));
+          dv[2 * j2 + 1] = g[x][8 * q + 2 * j2 + 1] * (a.om * __builtin_amdgcn_cosf(r1));
+          sv[2 * j2] = __builtin_amdgcn_sinf(r0);
+          sv[2 * j2 + 1] = __builtin_amdgcn_sinf(r1);
+        }
+        a.Dout[((pb_begin + k * pb_step) * KSI + ks) * 64 + lane] =
+            u32x4{OpBF16::pack2(dv[0], dv[1]), OpBF16::pack2(dv[2], dv[3]), OpBF16::pack2(dv[4], dv[5]),
+                  OpBF16::pack2(dv[6], dv[7])};
+        *pp = u32x4{OpBF16::pack2(sv[0], sv[1]), OpBF16::pack2(sv[2], sv[3]), OpBF16::pack2(sv[4], sv[5]),
+                    OpBF16::pack2(sv[6], sv[7])};
       }
+    }
+  };
+  auto phase_w = [&](int k) {
+    const char* sD = smem + (k & (NB - 1)) * BLK;
+    const char* sP = sD + KSJ * 1024;
 #pragma unroll
-      for (int x = 0; x < XT; ++x) {
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 fa[WJ], fb[WI];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int ks = 2 * (xit0 + x) + q;
-          u32x4* pp = reinterpret_cast<u32x4*>(sP + (bi * KSI + ks) * 1024) + lane;
-          const u32x4 p = *pp;
-          float dv[8], sv[8];
+      for (int x = 0; x < WJ; ++x)
+        fa[x] = ds_read_tr_pair(sD, tr_addr(wr * WJ + x, kk, 0, lane), tr_addr(wr * WJ + x, kk, 1, lane));
 #pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2) {
-            const float r0 = (float)(p[j2] & 0xffffu) * kInv65535, r1 = (float)(p[j2] >> 16) * kInv65535;
-            dv[2 * j2] = g[x][8 * q + 2 * j2] * (a.om * __builtin_amdgcn_cosf(r0));
-            dv[2 * j2 + 1] = g[x][8 * q + 2 * j2 + 1] * (a.om * __builtin_amdgcn_cosf(r1));
-            sv[2 * j2] = __builtin_amdgcn_sinf(r0);
-            sv[2 * j2 + 1] = __builtin_amdgcn_sinf(r1);
-          }
-          a.Dout[((pb + bi) * KSI + ks) * 64 + lane] =
-              u32x4{OpBF16::pack2(dv[0], dv[1]), OpBF16::pack2(dv[2], dv[3]), OpBF16::pack2(dv[4], dv[5]),
-                    OpBF16::pack2(dv[6], dv[7])};
-          *pp = u32x4{OpBF16::pack2(sv[0], sv[1]), OpBF16::pack2(sv[2], sv[3]), OpBF16::pack2(sv[4], sv[5]),
-                      OpBF16::pack2(sv[6], sv[7])};
+      for (int y = 0; y < WI; ++y)
+        fb[y] = ds_read_tr_pair(sP, tr_addr(wc * WI + y, kk, 0, lane), tr_addr(wc * WI + y, kk, 1, lane));
+#pragma unroll
+      for (int x = 0; x < WJ; ++x)
+#pragma unroll
+        for (int y = 0; y < WI; ++y) acc[x][y] = OpBF16::mfma(fa[x], fb[y], acc[x][y]);
+      if (wc == 0) {
+#pragma unroll
+        for (int x = 0; x < WJ; ++x) {
+          float tsum = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tsum += bf16_lo(fa[x][e]) + bf16_hi(fa[x][e]);
+          dbs[x] += tsum;
         }
       }
     }
-    bar_lds();                                     // activations in place (keeps tile t+1's DMA in flight)
-    // ---------------- phase W: dW += delta^T * act ----------------
-#pragma unroll
-    for (int bi = 0; bi < PBS; ++bi) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        u32x4 fa[WJ], fb[WI];
-#pragma unroll
-        for (int x = 0; x < WJ; ++x)
-          fa[x] = ds_read_tr_pair(sD + bi * KSJ * 1024, tr_addr(wr * WJ + x, kk, 0, lane),
-                                  tr_addr(wr * WJ + x, kk, 1, lane));
-#pragma unroll
-        for (int y = 0; y < WI; ++y)
-          fb[y] = ds_read_tr_pair(sP + bi * KSI * 1024, tr_addr(wc * WI + y, kk, 0, lane),
-                                  tr_addr(wc * WI + y, kk, 1, lane));
-#pragma unroll
-        for (int x = 0; x < WJ; ++x)
-#pragma unroll
-          for (int y = 0; y < WI; ++y) acc[x][y] = OpBF16::mfma(fa[x], fb[y], acc[x][y]);
-        if (wc == 0) {
-#pragma unroll
-          for (int x = 0; x < WJ; ++x) {
-            float tsum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tsum += bf16_lo(fa[x][e]) + bf16_hi(fa[x][e]);
-            dbs[x] += tsum;
-          }
-        }
-      }
+  };
+
+  if (nblk > 0) {
+    bar_all();                          // block 0 landed
+    if (2 < nblk) stage(2);
+    asm volatile("" ::: "memory");
+    phase_x(0);
+    for (int k = 1; k < nblk; ++k) {
+      // block k landed (issued two steps ago; younger: S_ST stores, one block of DMA, S_ST stores) and every
+      // wave finished step k-1
+      if (k >= 2 && k + 1 < nblk) bar_dma<2 * S_ST + G_MIN>(); else bar_all();
+      if (k + 2 < nblk) stage(k + 2);
+      asm volatile("" ::: "memory");
+      phase_x(k);
+      phase_w(k - 1);
     }
+    bar_lds();
+    phase_w(nblk - 1);
   }
   float* slab = a.slab + (size_t)blockIdx.x * (JW * IW + JW);
   const int cl = lane & 31, hh = lane >> 5;
@@ -634,6 +658,31 @@ __global__ void k_reduce(ReduceArgs a) {
     float s = 0.f;
     for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz];
     a.gb[j] = a.accumulate ? a.gb[j] + s : s;
+  }
+}
+
+// Vectorised form for hidden layers, whose slab layout [W rows*cols | b rows] IS the flat-gradient
+// layout: out[i] = sum_w slab[w][i].  256 threads = 32 float4 columns x 8 slab groups; group g sums
+// slabs g, g+8, ... in order, groups are combined 0..7 in order (fixed order => deterministic).
+__global__ __launch_bounds__(256) void k_reduce_vec(const float* slab, int n_wg, long stride, int n4, float* out,
+                                                    int accumulate) {
+  __shared__ f32x4 sh[8][32];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i4 = blockIdx.x * 32 + col;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < n4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(slab) + i4;
+    const long st4 = stride / 4;
+    for (int w = grp; w < n_wg; w += 8) s += p[w * st4];
+  }
+  sh[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && i4 < n4) {
+    f32x4 t = sh[0][col];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += sh[g][col];
+    f32x4* o = reinterpret_cast<f32x4*>(out) + i4;
+    *o = accumulate ? *o + t : t;
   }
 }
 
