@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="per-image", choices=["per-image", "pixel-split"],
+                    help="N>1: per-image = one independent fit per GPU (weak scaling, no collective); "
+                         "pixel-split = ONE image, rows sharded over ranks, gradient all-reduce over RCCL (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,29 +104,43 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     H = W = args.size
+    split = args.mode == "pixel-split" and world > 1
+    r0, r1 = (0, H)
+    if split:
+        from implicit_image.parallel import PixelSplitFit, shard_rows
+        r0, r1 = shard_rows(H, world, rank)
     eng = SirenEngine(H, W, args.hidden, args.depth, compute_dtype=args.dtype, device=local_rank,
-                      chunk_pixels=args.chunk)
+                      chunk_pixels=args.chunk, row_begin=r0, row_end=r1)
     # per-image sharding: every rank fits its own synthetic image (seed offset by rank), same init
     from implicit_image.models import Siren   # seed-0 SIREN init, random-init weights
     torch.manual_seed(0)
     init = Siren(depth=args.depth, hidden_size=args.hidden, first_omega_0=50.0, hidden_omega_0=30.0)
     eng.set_params(torch.cat([q.detach().reshape(-1) for q in init.parameters()]).to(dev))
     eng.set_coords(torch.linspace(0, 1, H).to(dev), torch.linspace(0, 1, W).to(dev))
-    img = device_image(H, W, dev, seed=1234 + rank)
+    img = device_image(H, W, dev, seed=1234 + (0 if split else rank))[r0:r1].contiguous()
     eng.set_target(img)
     lr = 3e-4
+    if split:
+        psf = PixelSplitFit(eng, 3 * H * W)
+
+    def run_steps(n):
+        if split:
+            for _ in range(n):
+                psf.step(lr)
+        else:
+            eng.step([lr] * n)          # no host sync inside: losses stay on the device
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    eng.step([lr] * args.warmup)
+    run_steps(args.warmup)
     barrier()
     eng.profile(True)
     eng.profile_reset()
     t0 = time.perf_counter()
-    eng.step([lr] * args.steps)          # no host sync inside: losses stay on the device
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -133,11 +150,15 @@ def main():
     rep = eng.profile_report()
     eng.profile(False)
     _, sse = eng.forward(want_pred=False)
+    if split:
+        t = torch.tensor([sse], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        sse = t.item()
     psnr = 10 * torch.log10(torch.tensor(3.0 * H * W / sse)).item()
 
     if rank == 0:
         F = flops_per_pixel_iter(args.hidden, args.depth)
-        value = world * H * W * args.steps / dt / 1e6
+        value = (1 if split else world) * H * W * args.steps / dt / 1e6
         kern = {k: v for k, v in rep.items() if v["launches"]}
         dom = max((k for k in kern if kern[k]["flops_per_launch"] > 0), key=lambda k: kern[k]["total_ms"])
         d = kern[dom]
@@ -146,13 +167,13 @@ def main():
         out = {
             "metric": "Mpixel-iters/s (fwd+bwd+Adam) @ SIREN-256x8",
             "value": value, "unit": "Mpixel-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if split else "weak",
             "vs_baseline": None, "dtype": "f16 fwd / bf16 bwd operands, f32 accumulate" if args.dtype == "f16" else "bf16",
             "data": "synthetic",
             "config": {"workload": f"siren_{args.hidden}x{args.depth}_fit_step_{H}x{W}x3_grid", "image": f"{H}x{W}x3",
-                       "hidden": args.hidden, "depth": args.depth, "sharding": f"per-image x{world}",
+                       "hidden": args.hidden, "depth": args.depth, "sharding": (f"pixel-split rows x{world} + RCCL grad all-reduce" if split else f"per-image x{world}"),
                        "chunk_pixels": eng.npix if args.chunk == 0 and eng.npix < (1 << 22) else (args.chunk or 1 << 22)},
-            "step_mfma_frac": value / world * 1e6 * F / (PEAK_BF16_TFLOPS * 1e12),
+            "step_mfma_frac": value / world * 1e6 * F / (PEAK_BF16_TFLOPS * 1e12),   # per GPU
             "psnr_after_run": psnr,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,

@@ -1,0 +1,94 @@
+"""`make fit` entry: the reference's fit loop (implicit_image/compress.py:54-170) on the HIP engine.
+
+    python -m implicit_image.fit [key=value ...]         # same override grammar as the Hydra entry
+
+Reads conf/ (implicit_image/config.py), builds the registry model, fits with train_epoch /
+update_connections / eval_epoch exactly in the reference's order, logs loss / PSNR / PSNR_8bit,
+and saves `model.pth` (fp32 state_dict with the reference's parameter names) in the run directory.
+Comma sweeps expand to a job list; under torch.distributed.run the jobs are sharded over ranks
+(per-image sharding: one fit per GPU, no collectives).
+"""
+import copy
+import json
+import logging
+import os
+import sys
+import time
+
+import torch
+
+from .config import Cfg, expand_sweeps, load_config
+from .data import get_grid, load_img
+from .models import registry as model_registry
+from .parallel import shard_jobs
+from .utils.train_helper import eval_epoch, get_device, get_optimizer_lr_scheduler, setup_mask, train_epoch
+
+REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+
+
+def fit_one(cfg: Cfg, device: torch.device, out_dir: str = None):
+    """One fit; returns dict(loss, PSNR, PSNR_8bit, steps, seconds)."""
+    torch.manual_seed(cfg.seed)                                                   # compress.py:58
+    img = load_img(**cfg.img)                                                      # compress.py:64
+    grid = get_grid(cfg.img.height, cfg.img.width)                                 # compress.py:67
+    small = cfg.masking.density if (cfg.get("masking") and cfg.masking.get("name") == "Small_Dense") else 1.0
+    eng_kw = dict(cfg.get("engine") or {})
+    model = model_registry[cfg.mlp.name](**cfg.mlp, small_dense_density=small, **eng_kw)   # compress.py:77
+    model, grid, img = model.to(device), grid.to(device), img.to(device)          # compress.py:84-86
+    model.train()
+    optim, lr_scheduler = get_optimizer_lr_scheduler(model, cfg.optim)             # compress.py:105
+    mult = cfg.train.multiplier
+    num_steps = cfg.train.num_steps * mult                                         # compress.py:110-120
+    mcfg = copy.deepcopy(cfg.get("masking")) if cfg.get("masking") else None
+    if mcfg:
+        if mcfg.get("end_when"):
+            mcfg.end_when = int(mcfg.end_when * mult)
+        if mcfg.get("interval"):
+            mcfg.interval = int(mcfg.interval * mult)
+    mask = setup_mask(model, optim, mcfg)                                          # compress.py:127
+    t0, last = time.time(), {}
+    for i in range(num_steps):                                                     # compress.py:137-170
+        train_epoch(model, optim, grid, img, lr_scheduler=lr_scheduler, mask=mask)
+        if mask and i <= mcfg.end_when and i % mcfg.interval == 0:
+            mask.update_connections()
+        if (i + 1) % cfg.train.log_steps == 0 or i + 1 == num_steps:
+            _, loss, psnr, psnr8 = eval_epoch(model, grid, img)
+            last = {"loss": loss, "PSNR": psnr, "PSNR_8bit": psnr8}
+            msg = f"Train | Step: {i + 1} | " + " | ".join(f"{k}: {v:.4f}" for k, v in last.items())
+            if mask:
+                msg += f" | Prune Rate: {mask.prune_rate:.4f} | Density: {mask.stats.total_density:.4f}"
+            logging.info(msg)
+    last.update(steps=num_steps, seconds=time.time() - t0)
+    if out_dir and cfg.train.save_weights:
+        os.makedirs(out_dir, exist_ok=True)
+        torch.save({"state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}},
+                   os.path.join(out_dir, "model.pth"))                            # compress.py:243-244
+        with open(os.path.join(out_dir, "result.json"), "w") as f:
+            json.dump(last, f)
+    return last
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    logging.basicConfig(level=logging.INFO, format="[%(asctime)s] %(message)s")
+    conf_dir = os.environ.get("IIC_CONF", os.path.join(REPO, "conf"))
+    jobs = expand_sweeps(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    results = []
+    for ov in shard_jobs(jobs, world, rank):
+        cfg = load_config(conf_dir, ov)
+        device = get_device(cfg.device)
+        if device.type == "cuda":
+            device = torch.device("cuda", local_rank)
+            torch.cuda.set_device(device)
+        tag = ",".join(o for o in ov if not o.startswith(("exp_name", "img.name"))) or "default"
+        out_dir = os.path.join("outputs", str(cfg.img.name), str(cfg.exp_name), tag.replace("/", "_"))
+        res = fit_one(cfg, device, out_dir)
+        logging.info(f"[rank {rank}] {tag}: {res}")
+        results.append((tag, res))
+    return results
+
+
+if __name__ == "__main__":
+    main()

@@ -305,3 +305,23 @@ def test_rigl_run_vs_reference_golden(golden):
     for n, w in model.named_parameters():
         if n in mask.mask_dict:
             assert torch.all(w.data[mask.mask_dict[n] == 0] == 0)
+
+
+def test_make_fit_entry_runs_the_reference_loop(tmp_path, monkeypatch):
+    """`make fit` path: conf/ loader -> registry model -> train/eval loop of compress.py:137-170."""
+    import os
+    from implicit_image.config import load_config
+    from implicit_image.fit import fit_one
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(tmp_path)
+    cfg = load_config(os.path.join(root, "conf"), ["img.height=64", "img.width=64", "img.seed=3", "mlp.hidden_size=64",
+                                                   "mlp.depth=4", "train.num_steps=100", "train.log_steps=50"])
+    res = fit_one(cfg, torch.device("cuda", 0), str(tmp_path / "out"))
+    p = so.siren_init(64, 4, seed=0)
+    img, grid, opt = so.synthetic_image(64, 64, seed=3), so.get_grid(64, 64), so.Adam(p)
+    for t in range(100):
+        so.train_epoch(p, opt, grid, img, t)
+    _, _, psnr_ref, _ = so.eval_epoch(p, grid, img)
+    assert abs(res["PSNR"] - psnr_ref) <= 0.05
+    sd = torch.load(tmp_path / "out" / "model.pth", weights_only=True)["state_dict"]
+    assert list(sd)[:2] == ["layers.0.linear.weight", "layers.0.linear.bias"]
