@@ -163,6 +163,15 @@ def main():
         dom = max((k for k in kern if kern[k]["flops_per_launch"] > 0), key=lambda k: kern[k]["total_ms"])
         d = kern[dom]
         avg_ms = d["total_ms"] / d["launches"]
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (same launch geometry:
+        # one 4 Mi-pixel chunk of SIREN 256x8); null for any other configuration
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_chunk4M.json")))
+            if args.hidden == 256 and args.depth == 8 and args.chunk == 0 and H * W >= (1 << 22) and dom in pmc["kernels"]:
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         ach = d["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
         out = {
             "metric": "Mpixel-iters/s (fwd+bwd+Adam) @ SIREN-256x8",
@@ -176,7 +185,8 @@ def main():
             "step_mfma_frac": value / world * 1e6 * F / (PEAK_BF16_TFLOPS * 1e12),   # per GPU
             "psnr_after_run": psnr,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": d["bytes_per_launch"],
                          "avg_launch_ms": avg_ms, "flops_per_launch": d["flops_per_launch"]},
             "kernels": {k: {"ms_per_step": v["total_ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
                             "tflops": (v["flops_per_launch"] * v["launches"] / (v["total_ms"] * 1e-3) / 1e12)

@@ -157,7 +157,10 @@ int launch_dw_t(sf_engine* h, const DwArgs& a, int n_wg) {
 
 template <int JW, int IW, int WR, int WC, bool LAST>
 int launch_bwd_t(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
-  const size_t lds = (size_t)4 * (JW / 16 + IW / 16) * 1024;
+  // 4-slot block ring + (widest configuration only) the parked quarter of the stationary weight rows
+  constexpr int NWV = WR * WC, XT = (IW / 32) / NWV, KSX = LAST ? 1 : JW / 16;
+  constexpr int WSP = (XT * KSX > 24) ? 4 : 0;
+  const size_t lds = (size_t)4 * (JW / 16 + IW / 16) * 1024 + (size_t)NWV * XT * WSP * 1024;
   int rc = set_lds(k_bwd<JW, IW, WR, WC, LAST>, lds);
   if (rc) return rc;
   hipLaunchKernelGGL((k_bwd<JW, IW, WR, WC, LAST>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
@@ -209,6 +212,7 @@ int refresh_images(sf_engine* h) {
     a.off_b[l] = h->off_b[l];
   }
   a.wscale = h->wscale;
+  a.om_first = h->cfg.first_omega_0; a.om_hidden = h->cfg.hidden_omega_0;
   a.fwd_is_f16 = h->cfg.compute_dtype == SF_F16;
   a.wf = h->wf; a.wf_last = h->wf_last; a.wb = h->wb; a.wb_last = h->wb_last;
   a.l0tab = h->l0tab;
@@ -296,7 +300,6 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         ba.wb = last ? reinterpret_cast<const u32x4*>(h->wb_last)
                      : reinterpret_cast<const u32x4*>(h->wb) + (size_t)(l - 1) * img_pieces;
         ba.n_pb = n_pb; ba.pb_per_wg = (int)pb_per_wg;
-        ba.om = (l - 1 == 0) ? h->cfg.first_omega_0 : h->cfg.hidden_omega_0;
         ba.slab = h->slab;
         const double rows = last ? h->cfg.out_features : WD;
         Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 4.0 * rows * WD * n_pb * 32.0,

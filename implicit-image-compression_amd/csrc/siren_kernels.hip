@@ -41,6 +41,10 @@ struct OpBF16 {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
   }
   static DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef SF_EXPERIMENT_NO_MFMA   // timing-only build: operands stay live, the matrix pipe stays idle
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
                                                    0, 0);
   }
@@ -63,6 +67,17 @@ DEV float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 DEV float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
 constexpr float kInv65535 = 1.0f / 65535.0f;
+
+// Phase decode for v_sin_f32 / v_cos_f32 (which take REVOLUTIONS and are 1-periodic): the unorm16 phase u
+// is dropped into the mantissa of a float in [1,2): x = 1 + u/65536 (+ <2^-16 from the neighbour's bits in
+// the high-half form).  Two integer ops per value instead of and/shift + cvt + mul; the 65535-vs-65536
+// scale (<=1.5e-5 rev) is below the quantisation step of the phase itself.
+#ifdef SF_EXPERIMENT_NO_TRANS   // timing-only build: no transcendentals in the backward epilogue
+#define __builtin_amdgcn_cosf(x) (x)
+#define __builtin_amdgcn_sinf(x) ((x) + 1.0f)
+#endif
+DEV float phase_rev_lo(uint32_t p) { return __builtin_bit_cast(float, ((p << 7) & 0x007fff80u) | 0x3f800000u); }
+DEV float phase_rev_hi(uint32_t p) { return __builtin_bit_cast(float, (p >> 9) | 0x3f800000u); }
 
 // workgroup barriers that do NOT drain in-flight global_load_lds (a plain __syncthreads() would)
 DEV void bar_lds() {
@@ -189,8 +204,10 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
                                              pack_phase2(ph[4], ph[5]), pack_phase2(ph[6], ph[7])};
   }
 
-  // one 32-neuron output tile: bias-initialised accumulator, KS MFMAs, sine epilogue
-  auto tile = [&](int nt, int l, u32x4* Bn) {
+  // One 32-neuron output tile = bias-initialised accumulator + KS MFMAs (tile_mma), then the sine epilogue
+  // (tile_epi).  The two are software-pipelined: the epilogue of tile k-1 (pure VALU + 2 stores) is issued
+  // in the shadow of the MFMAs of tile k: per MFMA ~4 VALU (mul, fract, sin, half a pack + half a pknorm).
+  auto tile_mma = [&](int nt) -> f32x16 {
     f32x16 acc;
     const float* bias = reinterpret_cast<const float*>(sW + IM::bias_piece(nt) * 64) + IM::bias_off(nt);
 #pragma unroll
@@ -201,6 +218,9 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
     const u32x4* wt = sW + IM::tile_piece(nt) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < KS; ++s) acc = OP::mfma(wt[s * 64], B[s], acc);
+    return acc;
+  };
+  auto tile_epi = [&](const f32x16& acc, int nt, int l, u32x4* Bn) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float av[8], ph[8];
@@ -218,30 +238,41 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
                   pack_phase2(ph[6], ph[7])};
     }
   };
-
   // ---- hidden layers: [WD x WD] on MFMA, activations stay in registers ------------------------
   for (int l = 1; l <= a.depth - 2; ++l) {
     const u32x4* img_l = a.wf + (size_t)(l - 1) * IM::PIECES * 64;
     u32x4 Bn[KS];
-    // half X of layer l landed (the stores of the previous half were issued after that DMA and may stay
-    // in flight); everyone left half Y of layer l-1
-    if (l == 1) bar_dma<TRAIN ? KS : 0>(); else bar_dma<TRAIN ? 2 * IM::H1 : 0>();
+    // half X of layer l landed (the epilogue stores issued after that DMA may stay in flight);
+    // everyone left half Y of layer l-1
+    if (l == 1) bar_dma<TRAIN ? KS : 0>(); else bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>();
     stage(img_l + IM::X_PIECES * 64, IM::X_PIECES, IM::Y_PIECES);
     asm volatile("" ::: "memory");
+    f32x16 prev = tile_mma(0);
 #pragma unroll
-    for (int nt = 0; nt < H0; ++nt) tile(nt, l, Bn);
-    bar_dma<TRAIN ? 2 * H0 : 0>();                // half Y landed; everyone left half X
+    for (int nt = 1; nt < H0; ++nt) {
+      const f32x16 cur = tile_mma(nt);
+      tile_epi(prev, nt - 1, l, Bn);
+      __builtin_amdgcn_sched_barrier(0);   // keep every epilogue next to its MFMA tile (no deferred sin blobs)
+      prev = cur;
+    }
+    bar_dma<TRAIN ? 2 * (H0 - 1) : 0>();          // half Y landed; everyone left half X
     if (l < a.depth - 2) stage(img_l + IM::PIECES * 64, 0, IM::X_PIECES);
     else stage(a.wf_last, 0, IM::LAST_PIECES);
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int nt = H0; nt < NT; ++nt) tile(nt, l, Bn);
+    for (int nt = H0; nt < NT; ++nt) {
+      const f32x16 cur = tile_mma(nt);
+      tile_epi(prev, nt - 1, l, Bn);
+      __builtin_amdgcn_sched_barrier(0);
+      prev = cur;
+    }
+    tile_epi(prev, NT - 1, l, Bn);
 #pragma unroll
     for (int s = 0; s < KS; ++s) B[s] = Bn[s];
   }
 
   // ---- last layer (out_features <= 3, padded to one 32-row tile) + residual ---------------------
-  if (a.depth > 2) bar_dma<TRAIN ? 2 * IM::H1 : 0>(); else bar_dma<TRAIN ? KS : 0>();
+  if (a.depth > 2) bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>(); else bar_dma<TRAIN ? KS : 0>();
   f32x16 acc;
   {
     const float* bias = reinterpret_cast<const float*>(sW + KS * 64);
@@ -464,7 +495,6 @@ struct BwdLayerArgs {
   const u32x4* wb;      // backward weight image of layer l: tiles (IW/32) x k-steps (KSX) x 64 lanes
   long n_pb;            // pixel blocks in this chunk
   int pb_per_wg;        // multiple of 2
-  float om;             // omega of layer l-1 (radians)
   float* slab;          // [gridDim.x][JW*IW + JW]
 };
 
@@ -487,12 +517,20 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   const int wr = wave / WAVES_C, wc = wave % WAVES_C;
   const int xit0 = wave * XT;
 
-  // stationary W^T rows of this wave
-  u32x4 wreg[XT][KSX];
+  // stationary W^T rows of this wave: k-steps [0, KSR) in registers, [KSR, KSX) parked in LDS behind the ring
+  // (the widest configuration needs the 32 registers: 256 accumulator + 128 weight registers leave too few)
+  constexpr int KSR = (XT * KSX > 24) ? KSX - 4 : KSX;
+  constexpr int WSP = KSX - KSR;                // spilled k-steps per row tile
+  char* sWsp = smem + NB * BLK + (size_t)wave * XT * WSP * 1024;
+  u32x4 wreg[XT][KSR];
 #pragma unroll
-  for (int x = 0; x < XT; ++x)
+  for (int x = 0; x < XT; ++x) {
 #pragma unroll
-    for (int s = 0; s < KSX; ++s) wreg[x][s] = a.wb[((xit0 + x) * KSX + s) * 64 + lane];
+    for (int s = 0; s < KSR; ++s) wreg[x][s] = a.wb[((xit0 + x) * KSX + s) * 64 + lane];
+#pragma unroll
+    for (int s = KSR; s < KSX; ++s)
+      reinterpret_cast<u32x4*>(sWsp + (x * WSP + s - KSR) * 1024)[lane] = a.wb[((xit0 + x) * KSX + s) * 64 + lane];
+  }
 
   f32x16 acc[WJ][WI];
 #pragma unroll
@@ -522,86 +560,119 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   //   X(k): delta_{k} B-pieces * stationary W^T -> G; epilogue: cos/sin of the phase piece this wave owns,
   //         delta_{l-1} to HBM, sin (bf16) written back IN PLACE over the phase piece
   //   W(k-1): dW += delta^T * act, both operands read transposed (ds_read_b64_tr_b16)
-  auto phase_x = [&](int k) {
-    char* sD = smem + (k & (NB - 1)) * BLK;
-    char* sP = sD + KSJ * 1024;
-    f32x16 g[XT];
+  // ---- pieces of one pipeline step (block kx in phase X, block kx-1 in phase W) ------------------
+  // With one wave per SIMD nothing but this wave can fill the shadow of its own MFMAs, and hipcc emits
+  // MFMA chains and VALU epilogues back to back.  The step is therefore cut into CHUNKS of 4 MFMAs +
+  // a quarter of an epilogue, separated by sched_barrier(0): the in-order issue then places ~25 VALU
+  // instructions (about 100-130 cycles) behind every 4 asynchronous MFMAs (128 cycles of matrix pipe).
+  constexpr int XC = KSX >= 4 ? 4 : 1;          // chunks per X tile
+  constexpr int XS = KSX / XC;                  // k-steps per chunk
+  auto x_mma_chunk = [&](int k, int x, int c, f32x16& g) {
+    const char* sD = smem + (k & (NB - 1)) * BLK;
 #pragma unroll
-    for (int x = 0; x < XT; ++x) g[x] = f32x16{};
-#pragma unroll
-    for (int s = 0; s < KSX; ++s) {
-      const u32x4 b = reinterpret_cast<const u32x4*>(sD + s * 1024)[lane];
-#pragma unroll
-      for (int x = 0; x < XT; ++x) g[x] = OpBF16::mfma(wreg[x][s], b, g[x]);
-    }
-#pragma unroll
-    for (int x = 0; x < XT; ++x) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int ks = 2 * (xit0 + x) + q;
-        u32x4* pp = reinterpret_cast<u32x4*>(sP + ks * 1024) + lane;
-        const u32x4 p = *pp;
-        float dv[8], sv[8];
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) {
-          const float r0 = (float)(p[j2] & 0xffffu) * kInv65535, r1 = (float)(p[j2] >> 16) * kInv65535;
-          dv[2 * j2] = g[x][8 * q + 2 * j2] * (a.om * __builtin_amdgcn_cosf(r0));
-          dv[2 * j2 + 1] = g[x][8 * q + 2 * j2 + 1] * (a.om * __builtin_amdgcn_cosf(r1));
-          sv[2 * j2] = __builtin_amdgcn_sinf(r0);
-          sv[2 * j2 + 1] = __builtin_amdgcn_sinf(r1);
-        }
-        a.Dout[((pb_begin + k * pb_step) * KSI + ks) * 64 + lane] =
-            u32x4{OpBF16::pack2(dv[0], dv[1]), OpBF16::pack2(dv[2], dv[3]), OpBF16::pack2(dv[4], dv[5]),
-                  OpBF16::pack2(dv[6], dv[7])};
-        *pp = u32x4{OpBF16::pack2(sv[0], sv[1]), OpBF16::pack2(sv[2], sv[3]), OpBF16::pack2(sv[4], sv[5]),
-                    OpBF16::pack2(sv[6], sv[7])};
-      }
+    for (int s = c * XS; s < (c + 1) * XS; ++s) {
+      const u32x4 w = s < KSR ? wreg[x][s < KSR ? s : 0]
+                              : reinterpret_cast<const u32x4*>(sWsp + (x * WSP + (s >= KSR ? s - KSR : 0)) * 1024)[lane];
+      g = OpBF16::mfma(w, reinterpret_cast<const u32x4*>(sD + s * 1024)[lane], g);
     }
   };
-  auto phase_w = [&](int k) {
+  // quarter c of the epilogue of row tile x: c>>1 selects the phase piece (q), c&1 the half of its 8 values
+  u32x4 ep_p, ep_d, ep_s;
+  auto x_epi_chunk = [&](int k, int x, int c, const f32x16& g) {
+    char* sP = smem + (k & (NB - 1)) * BLK + KSJ * 1024;
+    const int q = c >> 1, hf = c & 1, ks = 2 * (xit0 + x) + q;
+    u32x4* pp = reinterpret_cast<u32x4*>(sP + ks * 1024) + lane;
+    if (hf == 0) ep_p = *pp;
+#pragma unroll
+    for (int j2 = 2 * hf; j2 < 2 * hf + 2; ++j2) {
+      const float r0 = phase_rev_lo(ep_p[j2]), r1 = phase_rev_hi(ep_p[j2]);
+      ep_d[j2] = OpBF16::pack2(g[8 * q + 2 * j2] * __builtin_amdgcn_cosf(r0),
+                               g[8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(r1));
+      ep_s[j2] = OpBF16::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
+    }
+    if (hf == 1) {
+      a.Dout[((pb_begin + k * pb_step) * KSI + ks) * 64 + lane] = ep_d;
+      *pp = ep_s;
+    }
+  };
+  u32x4 fa[WJ], fb[WI];
+  auto w_load = [&](int k, int kk) {   // both operands of the dW product, read transposed from the ring slot
     const char* sD = smem + (k & (NB - 1)) * BLK;
     const char* sP = sD + KSJ * 1024;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      u32x4 fa[WJ], fb[WI];
+    for (int x = 0; x < WJ; ++x)
+      fa[x] = ds_read_tr_pair(sD, tr_addr(wr * WJ + x, kk, 0, lane), tr_addr(wr * WJ + x, kk, 1, lane));
 #pragma unroll
-      for (int x = 0; x < WJ; ++x)
-        fa[x] = ds_read_tr_pair(sD, tr_addr(wr * WJ + x, kk, 0, lane), tr_addr(wr * WJ + x, kk, 1, lane));
+    for (int y = 0; y < WI; ++y)
+      fb[y] = ds_read_tr_pair(sP, tr_addr(wc * WI + y, kk, 0, lane), tr_addr(wc * WI + y, kk, 1, lane));
+  };
+  auto w_mma_chunk = [&](int x) {
 #pragma unroll
-      for (int y = 0; y < WI; ++y)
-        fb[y] = ds_read_tr_pair(sP, tr_addr(wc * WI + y, kk, 0, lane), tr_addr(wc * WI + y, kk, 1, lane));
+    for (int y = 0; y < WI; ++y) acc[x][y] = OpBF16::mfma(fa[x], fb[y], acc[x][y]);
+  };
+  auto db_chunk = [&](int x) {
+    if (wc == 0) {
+      float tsum = 0.f;
 #pragma unroll
-      for (int x = 0; x < WJ; ++x)
+      for (int e = 0; e < 4; ++e) tsum += bf16_lo(fa[x][e]) + bf16_hi(fa[x][e]);
+      dbs[x] += tsum;
+    }
+  };
+  auto step = [&](int kx, bool do_x, bool do_w) {
+    f32x16 gp = {}, gc = {};
+    if (do_x) {
 #pragma unroll
-        for (int y = 0; y < WI; ++y) acc[x][y] = OpBF16::mfma(fa[x], fb[y], acc[x][y]);
-      if (wc == 0) {
+      for (int c = 0; c < XC; ++c) x_mma_chunk(kx, 0, c, gp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int x = 0; x < WJ; ++x) {
-          float tsum = 0.f;
+    for (int x = 1; x < XT; ++x) {
+      if (do_x) {
+        gc = f32x16{};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) tsum += bf16_lo(fa[x][e]) + bf16_hi(fa[x][e]);
-          dbs[x] += tsum;
+        for (int c = 0; c < 4; ++c) {
+          if (c < XC) x_mma_chunk(kx, x, c, gc);
+          x_epi_chunk(kx, x - 1, c, gp);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        gp = gc;
       }
     }
+    if (do_w) w_load(kx - 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (do_w) {
+#pragma unroll
+        for (int x = c * WJ / 4; x < (c + 1) * WJ / 4; ++x) { w_mma_chunk(x); db_chunk(x); }
+      }
+      if (do_x) x_epi_chunk(kx, XT - 1, c, gp);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (do_w) {
+      w_load(kx - 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < WJ; ++x) { w_mma_chunk(x); db_chunk(x); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   if (nblk > 0) {
     bar_all();                          // block 0 landed
     if (2 < nblk) stage(2);
     asm volatile("" ::: "memory");
-    phase_x(0);
+    step(0, true, false);
     for (int k = 1; k < nblk; ++k) {
       // block k landed (issued two steps ago; younger: S_ST stores, one block of DMA, S_ST stores) and every
       // wave finished step k-1
       if (k >= 2 && k + 1 < nblk) bar_dma<2 * S_ST + G_MIN>(); else bar_all();
       if (k + 2 < nblk) stage(k + 2);
       asm volatile("" ::: "memory");
-      phase_x(k);
-      phase_w(k - 1);
+      step(k, true, true);
     }
     bar_lds();
-    phase_w(nblk - 1);
+    step(nblk, false, true);
   }
   float* slab = a.slab + (size_t)blockIdx.x * (JW * IW + JW);
   const int cl = lane & 31, hh = lane >> 5;
@@ -730,6 +801,7 @@ struct ImgArgs {
   int depth, WD, out_features;
   long off_w[16], off_b[16];
   float wscale;             // forward-image scale (power of two)
+  float om_first, om_hidden; // backward images carry omega of layer l-1: d sin(om z)/dz = om cos(om z)
   int fwd_is_f16;
   uint16_t* wf; uint16_t* wf_last; uint16_t* wb; uint16_t* wb_last;
   f32x4* l0tab;
@@ -764,7 +836,7 @@ __global__ void k_images(ImgArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const float* Wl = a.params + a.off_w[l];
     const float wfwd = Wl[(long)(32 * tile + r) * WD + 16 * s + pi_perm(h, j)] * a.wscale;
-    const float wbwd = Wl[(long)(16 * s + pi_perm(h, j)) * WD + 32 * tile + r];
+    const float wbwd = Wl[(long)(16 * s + pi_perm(h, j)) * WD + 32 * tile + r] * (l - 1 == 0 ? a.om_first : a.om_hidden);
     const long dst = ((long)(l - 1) * G.PIECES + G.tile_piece(tile) + s) * 512 + lane * 8 + j;
     a.wf[dst] = a.fwd_is_f16 ? to_f16(wfwd) : to_bf16(wfwd);
     a.wb[gid] = to_bf16(wbwd);
@@ -797,7 +869,8 @@ __global__ void k_images(ImgArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int c = pi_perm(h, j);
     float w = 0.f;
-    if (c < a.out_features) w = a.params[a.off_w[L] + (long)c * WD + 32 * tile + r];
+    if (c < a.out_features)
+      w = a.params[a.off_w[L] + (long)c * WD + 32 * tile + r] * (L - 1 == 0 ? a.om_first : a.om_hidden);
     a.wb_last[gid] = to_bf16(w);
   }
   if (gid < WD) {

@@ -11,7 +11,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libsiren_fit.so"))
+# SIREN_FIT_LIB: developer override to A/B kernel variants built side by side (same C ABI)
+_LIB_PATH = os.environ.get("SIREN_FIT_LIB") or os.path.normpath(os.path.join(_HERE, "..", "csrc", "libsiren_fit.so"))
 
 SF_ABI_VERSION = 1
 DTYPES = {"bf16": 0, "f16": 1}

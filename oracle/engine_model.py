@@ -7,8 +7,8 @@ separate "rounding" (engine == this model to ~1e-5) from "algorithm" (this model
   forward  hidden / last GEMM operands rounded to fp16 (weights pre-scaled by 2^8) or bf16, f32 accumulate;
            layer 0 in f32; sine computed on z*omega/(2 pi) revolutions;
   spill    only the PHASE frac(z*omega/2pi) as unorm16 (x*65535, round-nearest-even);
-  backward all GEMM operands bf16: delta_l = bf16(G * omega * cos(2 pi q/65535)), activations
-           re-derived as bf16(sin(2 pi q/65535)); dL/dout = bf16(resid/(3N)); layer-0 coordinates
+  backward all GEMM operands bf16: delta_l = bf16((delta W*omega) * cos(2 pi q/65536)), activations
+           re-derived as bf16(sin(2 pi q/65536)), backward weight image = bf16(W * omega_{l-1}); dL/dout = bf16(resid/(3N)); layer-0 coordinates
            split x = bf16(x) + bf16(x - bf16(x)).
 """
 import math
@@ -61,13 +61,14 @@ def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torc
     delta = _rt(resid * gscale, "bf16")
     grads = [None] * (2 * depth)
     for l in range(L, 0, -1):
-        ph = q[l - 1] * (1.0 / 65535.0)
+        # backward phase decode: u dropped into a float mantissa -> u/65536 revolutions (k_bwd phase_rev_*)
+        ph = q[l - 1] * (1.0 / 65536.0)
         act = _rt(torch.sin(TWO_PI * ph.double()).float(), "bf16")
         grads[2 * l] = delta.t() @ act
         grads[2 * l + 1] = delta.sum(0)
         om = first_omega_0 if l - 1 == 0 else hidden_omega_0
-        G = delta @ _rt(params[2 * l], "bf16")
-        delta = _rt(G * (om * torch.cos(TWO_PI * ph.double()).float()), "bf16")
+        G = delta @ _rt(params[2 * l] * om, "bf16")          # omega of layer l-1 is folded into the bf16 image
+        delta = _rt(G * torch.cos(TWO_PI * ph.double()).float(), "bf16")
     xh = _rt(x, "bf16")
     xl = _rt(x - xh, "bf16")
     grads[0] = delta.t() @ xh + delta.t() @ xl
