@@ -56,6 +56,7 @@ struct sf_engine {
   f32x4* l0tab = nullptr;
   bool images_dirty = true;
   float wscale = 1.f;
+  float gpre = 1.f;       // power-of-two pre-scale of dL/dout (fp16 backward operands), undone in k_reduce*
   // data
   float *gh = nullptr, *gw = nullptr;
   bool have_coords = false;
@@ -89,8 +90,8 @@ struct Launch {  // RAII-less helper: brackets a kernel launch with events when 
       hipEventCreate(&r.e0);
       hipEventCreate(&r.e1);
       hipEventRecord(r.e0, h->stream);
-      h->prof_flops[id] = flops;
-      h->prof_bytes[id] = bytes;
+      h->prof_flops[id] += flops;   // totals; sf_profile_get reports the per-launch average
+      h->prof_bytes[id] += bytes;
     }
   }
   void done() {
@@ -145,36 +146,52 @@ int launch_fwd_t(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
   return SF_OK;
 }
 
+template <int ROWS, int COLS, int WR, int WC, int BSRC, typename OP>
+int launch_dw_to(sf_engine* h, const DwArgs& a, int n_wg) {
+  const size_t lds = (size_t)2 * (ROWS / 16 + COLS / 16) * 1024;
+  int rc = set_lds(k_dw<ROWS, COLS, WR, WC, BSRC, OP>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_dw<ROWS, COLS, WR, WC, BSRC, OP>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
 template <int ROWS, int COLS, int WR, int WC, int BSRC>
 int launch_dw_t(sf_engine* h, const DwArgs& a, int n_wg) {
-  const size_t lds = (size_t)2 * (ROWS / 16 + COLS / 16) * 1024;
-  int rc = set_lds(k_dw<ROWS, COLS, WR, WC, BSRC>, lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL((k_dw<ROWS, COLS, WR, WC, BSRC>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
-  HIPCHK(hipGetLastError());
-  return SF_OK;
+  return h->cfg.compute_dtype == SF_F16 ? launch_dw_to<ROWS, COLS, WR, WC, BSRC, OpF16>(h, a, n_wg)
+                                        : launch_dw_to<ROWS, COLS, WR, WC, BSRC, OpBF16>(h, a, n_wg);
 }
 
-template <int JW, int IW, int WR, int WC, bool LAST>
-int launch_bwd_t(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
-  // 4-slot block ring + (widest configuration only) the parked quarter of the stationary weight rows
+template <int JW, int IW, int WR, int WC, bool LAST, bool P0, typename OP>
+int launch_bwd_tpo(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
+  // 4-slot block ring + (widest configuration only) the parked part of the stationary weight rows
+  // + (P0) the layer-0 table
   constexpr int NWV = WR * WC, XT = (IW / 32) / NWV, KSX = LAST ? 1 : JW / 16;
-  constexpr int WSP = (XT * KSX > 24) ? 4 : 0;
-  const size_t lds = (size_t)4 * (JW / 16 + IW / 16) * 1024 + (size_t)NWV * XT * WSP * 1024;
-  int rc = set_lds(k_bwd<JW, IW, WR, WC, LAST>, lds);
+  constexpr int WSP = (XT * KSX > 24) ? (P0 ? 3 : 4) : 0;
+  const size_t lds = (size_t)4 * (JW / 16 + IW / 16) * 1024 + (size_t)NWV * XT * WSP * 1024 + (P0 ? (size_t)IW * 16 : 0);
+  int rc = set_lds(k_bwd<JW, IW, WR, WC, LAST, P0, OP>, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_bwd<JW, IW, WR, WC, LAST>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
+  hipLaunchKernelGGL((k_bwd<JW, IW, WR, WC, LAST, P0, OP>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
   HIPCHK(hipGetLastError());
   return SF_OK;
 }
+template <int JW, int IW, int WR, int WC, bool LAST, bool P0>
+int launch_bwd_tp(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
+  return h->cfg.compute_dtype == SF_F16 ? launch_bwd_tpo<JW, IW, WR, WC, LAST, P0, OpF16>(h, a, n_wg)
+                                        : launch_bwd_tpo<JW, IW, WR, WC, LAST, P0, OpBF16>(h, a, n_wg);
+}
+template <int JW, int IW, int WR, int WC, bool LAST>
+int launch_bwd_t(sf_engine* h, const BwdLayerArgs& a, int n_wg, bool p0) {
+  return p0 ? launch_bwd_tp<JW, IW, WR, WC, LAST, true>(h, a, n_wg) : launch_bwd_tp<JW, IW, WR, WC, LAST, false>(h, a, n_wg);
+}
 
-// fused backward of one layer: last = the out_features(<=3, padded to 32)-row layer
-int launch_bwd(sf_engine* h, bool last, const BwdLayerArgs& a, int n_wg) {
+// fused backward of one layer: last = the out_features(<=3, padded to 32)-row layer; p0 = its input layer is
+// layer 0, whose phases are re-derived from the coordinates
+int launch_bwd(sf_engine* h, bool last, bool p0, const BwdLayerArgs& a, int n_wg) {
   switch (h->WD) {
-    case 32: return last ? launch_bwd_t<32, 32, 1, 1, true>(h, a, n_wg) : launch_bwd_t<32, 32, 1, 1, false>(h, a, n_wg);
-    case 64: return last ? launch_bwd_t<32, 64, 1, 2, true>(h, a, n_wg) : launch_bwd_t<64, 64, 2, 1, false>(h, a, n_wg);
-    case 128: return last ? launch_bwd_t<32, 128, 1, 4, true>(h, a, n_wg) : launch_bwd_t<128, 128, 2, 2, false>(h, a, n_wg);
-    case 256: return last ? launch_bwd_t<32, 256, 1, 8, true>(h, a, n_wg) : launch_bwd_t<256, 256, 2, 2, false>(h, a, n_wg);
+    case 32: return last ? launch_bwd_t<32, 32, 1, 1, true>(h, a, n_wg, p0) : launch_bwd_t<32, 32, 1, 1, false>(h, a, n_wg, p0);
+    case 64: return last ? launch_bwd_t<32, 64, 1, 2, true>(h, a, n_wg, p0) : launch_bwd_t<64, 64, 2, 1, false>(h, a, n_wg, p0);
+    case 128: return last ? launch_bwd_t<32, 128, 1, 4, true>(h, a, n_wg, p0) : launch_bwd_t<128, 128, 2, 2, false>(h, a, n_wg, p0);
+    case 256: return last ? launch_bwd_t<32, 256, 1, 8, true>(h, a, n_wg, p0) : launch_bwd_t<256, 256, 2, 2, false>(h, a, n_wg, p0);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
@@ -265,13 +282,13 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     fa.sc_last = 1.0f / h->wscale;
     fa.P = h->Pbuf; fa.p_stride = h->p_stride; fa.Dlast = h->Dlast;
     fa.img = h->img;
-    fa.gscale = (float)(1.0 / (3.0 * h->n_total));
+    fa.gscale = (float)((double)h->gpre / (3.0 * h->n_total));
     fa.pred = pred;
     fa.sse_part = h->sse_part + sse_off;
     sse_off += n_super;
     {
       Launch L(h, K_FWD, flops_fwd_px(h) * n_pb * 32.0,
-               n_pb * 32.0 * (12.0 + (train ? (D - 1) * WD * 2.0 + 64.0 : 0.0)));
+               n_pb * 32.0 * (12.0 + (train ? (D - 2) * WD * 2.0 + 64.0 : 0.0)));
       rc = launch_fwd(h, fa, n_super, train);
       L.done();
       if (rc) return rc;
@@ -288,7 +305,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     for (int l = D - 1; l >= 0; --l) {
       ReduceArgs ra;
       memset(&ra, 0, sizeof(ra));
-      ra.slab = h->slab; ra.n_wg = n_wg; ra.accumulate = c > 0;
+      ra.slab = h->slab; ra.n_wg = n_wg; ra.accumulate = c > 0; ra.scale = 1.0f / h->gpre;
       ra.gW = h->grads + h->off_w[l]; ra.gb = h->grads + h->off_b[l];
       if (l > 0) {
         const bool last = l == D - 1;
@@ -301,10 +318,16 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
                      : reinterpret_cast<const u32x4*>(h->wb) + (size_t)(l - 1) * img_pieces;
         ba.n_pb = n_pb; ba.pb_per_wg = (int)pb_per_wg;
         ba.slab = h->slab;
+        const bool p0 = l - 1 == 0;
+        ba.l0tab = h->l0tab; ba.pix0 = pix0; ba.npix = h->npix; ba.W = h->cfg.width; ba.row_begin = h->cfg.row_begin;
+        ba.w_magic = ((1ULL << 40) + (unsigned long long)h->cfg.width - 1) / (unsigned long long)h->cfg.width;
+        ba.inv_hm1 = h->cfg.height > 1 ? 1.0f / (float)(h->cfg.height - 1) : 0.f;
+        ba.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
+        ba.sc_first = fa.sc_first;
         const double rows = last ? h->cfg.out_features : WD;
         Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 4.0 * rows * WD * n_pb * 32.0,
-                 n_pb * 32.0 * ((last ? 64.0 : WD * 2.0) + WD * 4.0));
-        rc = launch_bwd(h, last, ba, n_wg);
+                 n_pb * 32.0 * ((last ? 64.0 : WD * 2.0) + WD * (p0 ? 2.0 : 4.0)));
+        rc = launch_bwd(h, last, p0, ba, n_wg);
         L.done();
         if (rc) return rc;
         ra.slab_rows = last ? 32 : WD; ra.slab_cols = WD;
@@ -327,7 +350,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         if (l > 0 && l < D - 1) {   // slab layout == flat gradient layout [W | b]
           const int n4 = n / 4;
           hipLaunchKernelGGL(k_reduce_vec, dim3((n4 + 31) / 32), dim3(256), 0, h->stream, (const float*)h->slab,
-                             n_wg, (long)n, n4, h->grads + h->off_w[l], (int)ra.accumulate);
+                             n_wg, (long)n, n4, h->grads + h->off_w[l], (int)ra.accumulate, ra.scale);
         } else {
           hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, h->stream, ra);
         }
@@ -407,6 +430,9 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   h->P = off;
   // fp16 forward images are scaled by 2^8 so that small weights stay normal numbers
   h->wscale = cfg->compute_dtype == SF_F16 ? 256.0f : 1.0f;
+  // fp16 backward operands: dL/dout = resid/(3N) is pre-scaled by 2^k ~ 4*3N so the deltas sit around 1
+  // (fp16 normal range 6e-5..65504); every gradient is multiplied back by 2^-k in the slab reduction
+  if (cfg->compute_dtype == SF_F16) h->gpre = (float)exp2(ceil(log2(3.0 * (double)cfg->height * (double)cfg->width)) + 2.0);
   // chunking
   long chunk = cfg->chunk_pixels > 0 ? cfg->chunk_pixels : (1L << 22);
   chunk = (chunk + kSuper - 1) / kSuper * kSuper;
@@ -607,7 +633,7 @@ int sf_profile_reset(sf_handle* h) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   int rc = prof_flush(h);
   if (rc) return rc;
-  for (int i = 0; i < K_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+  for (int i = 0; i < K_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; h->prof_flops[i] = 0; h->prof_bytes[i] = 0; }
   return SF_OK;
 }
 int sf_profile_num_kernels(const sf_handle* h, int32_t* n) {
@@ -623,8 +649,9 @@ int sf_profile_get(sf_handle* h, int32_t idx, const char** name, double* total_m
   if (name) *name = kKernelNames[idx];
   if (total_ms) *total_ms = h->prof_ms[idx];
   if (launches) *launches = h->prof_n[idx];
-  if (flops_per_launch) *flops_per_launch = h->prof_flops[idx];
-  if (bytes_per_launch) *bytes_per_launch = h->prof_bytes[idx];
+  const double nl = h->prof_n[idx] > 0 ? (double)h->prof_n[idx] : 1.0;
+  if (flops_per_launch) *flops_per_launch = h->prof_flops[idx] / nl;
+  if (bytes_per_launch) *bytes_per_launch = h->prof_bytes[idx] / nl;
   return SF_OK;
 }
 

@@ -40,6 +40,10 @@ struct OpBF16 {
     f32x2 v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
   }
+  static DEV float sum2(uint32_t u) {
+    return __builtin_bit_cast(float, u << 16) + __builtin_bit_cast(float, u & 0xffff0000u);
+  }
+  static DEV float lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
   static DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
 #ifdef SF_EXPERIMENT_NO_MFMA   // timing-only build: operands stay live, the matrix pipe stays idle
     asm volatile("" ::"v"(a), "v"(b));
@@ -54,6 +58,11 @@ struct OpF16 {
     f32x2 v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
   }
+  static DEV float sum2(uint32_t u) {   // lo + hi element of a packed pair, in fp32
+    const f16x2 v = __builtin_bit_cast(f16x2, u);
+    return (float)v[0] + (float)v[1];
+  }
+  static DEV float lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
   static DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
                                                   0);
@@ -189,19 +198,15 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   // ---- layer 0: K = 2, f32 VALU, written straight into B-fragment order -----------------------
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    float av[8], ph[8];
+    float av[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const f32x4 t = sL0[16 * s + pi_perm(h, j)];
       const float z = __builtin_fmaf(t.y, x1, __builtin_fmaf(t.x, x0, t.z));
-      const float tt = z * a.sc_first;
-      av[j] = __builtin_amdgcn_sinf(tt);
-      ph[j] = __builtin_amdgcn_fractf(tt);
+      av[j] = __builtin_amdgcn_sinf(z * a.sc_first);
     }
     B[s] = u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]), OP::pack2(av[6], av[7])};
-    if (TRAIN)
-      a.P[(pb * KS + s) * 64 + lane] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]),
-                                             pack_phase2(ph[4], ph[5]), pack_phase2(ph[6], ph[7])};
+    // layer-0 phases are NOT spilled: k_bwd re-derives them from the coordinates (2 FMAs per value)
   }
 
   // One 32-neuron output tile = bias-initialised accumulator + KS MFMAs (tile_mma), then the sine epilogue
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
     u32x4 Bn[KS];
     // half X of layer l landed (the epilogue stores issued after that DMA may stay in flight);
     // everyone left half Y of layer l-1
-    if (l == 1) bar_dma<TRAIN ? KS : 0>(); else bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>();
+    if (l == 1) bar_dma<0>(); else bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>();
     stage(img_l + IM::X_PIECES * 64, IM::X_PIECES, IM::Y_PIECES);
     asm volatile("" ::: "memory");
     f32x16 prev = tile_mma(0);
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   }
 
   // ---- last layer (out_features <= 3, padded to one 32-row tile) + residual ---------------------
-  if (a.depth > 2) bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>(); else bar_dma<TRAIN ? KS : 0>();
+  if (a.depth > 2) bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>(); else bar_dma<0>();
   f32x16 acc;
   {
     const float* bias = reinterpret_cast<const float*>(sW + KS * 64);
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   }
   if (TRAIN) {
     // dL/dout in F-layout (k-step 0: neurons PI(0,j) = j for j < 4), second k-step zero
-    a.Dlast[(pb * 2 + 0) * 64 + lane] = u32x4{OpBF16::pack2(d[0], d[1]), OpBF16::pack2(d[2], 0.f), 0u, 0u};
+    a.Dlast[(pb * 2 + 0) * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
     a.Dlast[(pb * 2 + 1) * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
   }
   // workgroup SSE partial (fixed order: lanes by xor-shuffle, then waves 0..7)
@@ -356,7 +361,7 @@ DEV u32x4 ds_read_tr_pair(const char* base, int off0, int off1) {
   return u32x4{a0.x, a0.y, a1.x, a1.y};
 }
 
-template <int ROWS, int COLS, int WAVES_R, int WAVES_C, int BSRC>
+template <int ROWS, int COLS, int WAVES_R, int WAVES_C, int BSRC, typename OP>
 __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_dw(DwArgs a) {
   constexpr int NW = WAVES_R * WAVES_C, NTHR = NW * 64;
   constexpr int JT = ROWS / 32, IT = COLS / 32;
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_dw(DwArgs a) {
           for (int j2 = 0; j2 < 4; ++j2) {
             const float s0 = __builtin_amdgcn_sinf((float)(p[j2] & 0xffffu) * kInv65535);
             const float s1 = __builtin_amdgcn_sinf((float)(p[j2] >> 16) * kInv65535);
-            o[j2] = OpBF16::pack2(s0, s1);
+            o[j2] = OP::pack2(s0, s1);
           }
         }
         reinterpret_cast<u32x4*>(sB)[i] = o;
@@ -418,9 +423,9 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_dw(DwArgs a) {
           if (pix >= a.npix) pix = a.npix - 1;
           const int row = (int)(pix / a.W), col = (int)(pix - (long)row * a.W);
           const float x0 = (a.gh[a.row_begin + row] - 0.5f) * 2.0f, x1 = (a.gw[col] - 0.5f) * 2.0f;
-          const float x0h = bf16_lo(OpBF16::pack2(x0, 0.f)), x1h = bf16_lo(OpBF16::pack2(x1, 0.f));
-          o[0] = OpBF16::pack2(x0h, x0 - x0h);
-          o[1] = OpBF16::pack2(x1h, x1 - x1h);
+          const float x0h = OP::lo(OP::pack2(x0, 0.f)), x1h = OP::lo(OP::pack2(x1, 0.f));
+          o[0] = OP::pack2(x0h, x0 - x0h);
+          o[1] = OP::pack2(x1h, x1 - x1h);
         }
         reinterpret_cast<u32x4*>(sB)[i] = o;
       }
@@ -443,13 +448,13 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_dw(DwArgs a) {
 #pragma unroll
         for (int x = 0; x < WJ; ++x)
 #pragma unroll
-          for (int y = 0; y < WI; ++y) acc[x][y] = OpBF16::mfma(fa[x], fb[y], acc[x][y]);
+          for (int y = 0; y < WI; ++y) acc[x][y] = OP::mfma(fa[x], fb[y], acc[x][y]);
         if (wc == 0) {
 #pragma unroll
           for (int x = 0; x < WJ; ++x) {
             float t = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t += bf16_lo(fa[x][e]) + bf16_hi(fa[x][e]);
+            for (int e = 0; e < 4; ++e) t += OP::sum2(fa[x][e]);
             dbs[x] += t;
           }
         }
@@ -496,9 +501,16 @@ struct BwdLayerArgs {
   long n_pb;            // pixel blocks in this chunk
   int pb_per_wg;        // multiple of 2
   float* slab;          // [gridDim.x][JW*IW + JW]
+  // P0 variant (layer l-1 is layer 0): its phases are re-derived from the pixel coordinates instead of read
+  const f32x4* l0tab;   // [IW] {w00, w01, b0, 0}
+  long pix0, npix;      // first local pixel of the chunk, local pixel count
+  int W, row_begin;
+  unsigned long long w_magic;   // ceil(2^40 / W): row = (p * w_magic) >> 40
+  float inv_hm1, inv_wm1;       // 1/(H-1), 1/(W-1) (0 when the extent is 1): torch.linspace(0,1,n)[i] ~ i/(n-1)
+  float sc_first;               // first_omega_0 / (2 pi)
 };
 
-template <int JW, int IW, int WAVES_R, int WAVES_C, bool LAST>
+template <int JW, int IW, int WAVES_R, int WAVES_C, bool LAST, bool P0, typename OP>
 __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   constexpr int NW = WAVES_R * WAVES_C;
   constexpr int JT = JW / 32, IT = IW / 32;
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   static_assert(IT % NW == 0, "phase-X tiling needs NW <= IT");
   constexpr int NB = 4;                       // LDS ring: blocks of 32 pixels
   constexpr int BLK = (KSJ + KSI) * 1024;     // bytes per ring slot: delta pieces then phase pieces
-  constexpr int G_MIN = KSJ / NW + KSI / NW;  // LDS-DMA instructions every wave issues per block (lower bound)
+  constexpr int G_MIN = KSJ / NW + (P0 ? 0 : KSI / NW);  // LDS-DMA instructions every wave issues per block (lower bound)
   constexpr int S_ST = 2 * XT;                // delta stores per wave per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
 
   // stationary W^T rows of this wave: k-steps [0, KSR) in registers, [KSR, KSX) parked in LDS behind the ring
   // (the widest configuration needs the 32 registers: 256 accumulator + 128 weight registers leave too few)
-  constexpr int KSR = (XT * KSX > 24) ? KSX - 4 : KSX;
+  constexpr int KSR = (XT * KSX > 24) ? KSX - (P0 ? 3 : 4) : KSX;   // (P0: the layer-0 table takes 4 KiB of LDS)
   constexpr int WSP = KSX - KSR;                // spilled k-steps per row tile
   char* sWsp = smem + NB * BLK + (size_t)wave * XT * WSP * 1024;
   u32x4 wreg[XT][KSR];
@@ -550,7 +562,22 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
     char* base = smem + (k & (NB - 1)) * BLK;
     const long pb = pb_begin + k * pb_step;
     for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * KSJ + pc) * 64 + lane, base + pc * 1024);
-    for (int pc = wave; pc < KSI; pc += NW) glds16(a.P + (pb * KSI + pc) * 64 + lane, base + (KSJ + pc) * 1024);
+    if (!P0)
+      for (int pc = wave; pc < KSI; pc += NW) glds16(a.P + (pb * KSI + pc) * 64 + lane, base + (KSJ + pc) * 1024);
+  };
+  // P0: layer-0 table in LDS (behind the parked weights) and this lane's pixel coordinates per block
+  const f32x4* sL0 = reinterpret_cast<const f32x4*>(smem + NB * BLK + (size_t)NW * XT * WSP * 1024);
+  if (P0) {
+    f32x4* dst = reinterpret_cast<f32x4*>(smem + NB * BLK + (size_t)NW * XT * WSP * 1024);
+    for (int i = tid; i < IW; i += NW * 64) dst[i] = a.l0tab[i];
+  }
+  auto pixel_xy = [&](int k, float& x0, float& x1) {
+    long p = a.pix0 + (pb_begin + (long)k * pb_step) * 32 + (lane & 31);
+    if (p >= a.npix) p = a.npix - 1;
+    const unsigned row = (unsigned)(((unsigned long long)p * a.w_magic) >> 40);
+    const unsigned col = (unsigned)(p - (long)row * a.W);
+    x0 = ((float)(row + (unsigned)a.row_begin) * a.inv_hm1 - 0.5f) * 2.0f;
+    x1 = ((float)col * a.inv_wm1 - 0.5f) * 2.0f;
   };
 
   if (nblk > 0) stage(0);
@@ -573,22 +600,30 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
     for (int s = c * XS; s < (c + 1) * XS; ++s) {
       const u32x4 w = s < KSR ? wreg[x][s < KSR ? s : 0]
                               : reinterpret_cast<const u32x4*>(sWsp + (x * WSP + (s >= KSR ? s - KSR : 0)) * 1024)[lane];
-      g = OpBF16::mfma(w, reinterpret_cast<const u32x4*>(sD + s * 1024)[lane], g);
+      g = OP::mfma(w, reinterpret_cast<const u32x4*>(sD + s * 1024)[lane], g);
     }
   };
   // quarter c of the epilogue of row tile x: c>>1 selects the phase piece (q), c&1 the half of its 8 values
   u32x4 ep_p, ep_d, ep_s;
+  float ep_x0 = 0.f, ep_x1 = 0.f;
   auto x_epi_chunk = [&](int k, int x, int c, const f32x16& g) {
     char* sP = smem + (k & (NB - 1)) * BLK + KSJ * 1024;
     const int q = c >> 1, hf = c & 1, ks = 2 * (xit0 + x) + q;
     u32x4* pp = reinterpret_cast<u32x4*>(sP + ks * 1024) + lane;
-    if (hf == 0) ep_p = *pp;
+    if (!P0 && hf == 0) ep_p = *pp;
 #pragma unroll
     for (int j2 = 2 * hf; j2 < 2 * hf + 2; ++j2) {
-      const float r0 = phase_rev_lo(ep_p[j2]), r1 = phase_rev_hi(ep_p[j2]);
-      ep_d[j2] = OpBF16::pack2(g[8 * q + 2 * j2] * __builtin_amdgcn_cosf(r0),
+      float r0, r1;
+      if (P0) {   // phase of layer 0 from the coordinates: neurons 16*ks + PI(h, 2*j2), +1
+        const f32x4 t0 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2)], t1 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2 + 1)];
+        r0 = __builtin_fmaf(t0.y, ep_x1, __builtin_fmaf(t0.x, ep_x0, t0.z)) * a.sc_first;
+        r1 = __builtin_fmaf(t1.y, ep_x1, __builtin_fmaf(t1.x, ep_x0, t1.z)) * a.sc_first;
+      } else {
+        r0 = phase_rev_lo(ep_p[j2]); r1 = phase_rev_hi(ep_p[j2]);
+      }
+      ep_d[j2] = OP::pack2(g[8 * q + 2 * j2] * __builtin_amdgcn_cosf(r0),
                                g[8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(r1));
-      ep_s[j2] = OpBF16::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
+      ep_s[j2] = OP::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
     }
     if (hf == 1) {
       a.Dout[((pb_begin + k * pb_step) * KSI + ks) * 64 + lane] = ep_d;
@@ -608,18 +643,19 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   };
   auto w_mma_chunk = [&](int x) {
 #pragma unroll
-    for (int y = 0; y < WI; ++y) acc[x][y] = OpBF16::mfma(fa[x], fb[y], acc[x][y]);
+    for (int y = 0; y < WI; ++y) acc[x][y] = OP::mfma(fa[x], fb[y], acc[x][y]);
   };
   auto db_chunk = [&](int x) {
     if (wc == 0) {
       float tsum = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tsum += bf16_lo(fa[x][e]) + bf16_hi(fa[x][e]);
+      for (int e = 0; e < 4; ++e) tsum += OP::sum2(fa[x][e]);
       dbs[x] += tsum;
     }
   };
   auto step = [&](int kx, bool do_x, bool do_w) {
     f32x16 gp = {}, gc = {};
+    if (P0 && do_x) pixel_xy(kx, ep_x0, ep_x1);
     if (do_x) {
 #pragma unroll
       for (int c = 0; c < XC; ++c) x_mma_chunk(kx, 0, c, gp);
@@ -705,6 +741,7 @@ struct ReduceArgs {
   float* gW;                        // [rows_out][cols_out]
   float* gb;                        // [rows_out]
   int accumulate;                   // add to the existing gradient (later chunks)
+  float scale;                      // 1 / gradient pre-scale (power of two; fp16 backward operands)
 };
 
 __global__ void k_reduce(ReduceArgs a) {
@@ -722,12 +759,14 @@ __global__ void k_reduce(ReduceArgs a) {
       const float* p = a.slab + (long)j * a.slab_cols + 2 * i;
       for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz] + p[w * slab_sz + 1];
     }
+    s *= a.scale;
     a.gW[idx] = a.accumulate ? a.gW[idx] + s : s;
   } else {
     const int j = idx - nW;
     const float* p = a.slab + (long)a.slab_rows * a.slab_cols + j;
     float s = 0.f;
     for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz];
+    s *= a.scale;
     a.gb[j] = a.accumulate ? a.gb[j] + s : s;
   }
 }
@@ -736,7 +775,7 @@ __global__ void k_reduce(ReduceArgs a) {
 // layout: out[i] = sum_w slab[w][i].  256 threads = 32 float4 columns x 8 slab groups; group g sums
 // slabs g, g+8, ... in order, groups are combined 0..7 in order (fixed order => deterministic).
 __global__ __launch_bounds__(256) void k_reduce_vec(const float* slab, int n_wg, long stride, int n4, float* out,
-                                                    int accumulate) {
+                                                    int accumulate, float scale) {
   __shared__ f32x4 sh[8][32];
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int i4 = blockIdx.x * 32 + col;
@@ -752,6 +791,7 @@ __global__ __launch_bounds__(256) void k_reduce_vec(const float* slab, int n_wg,
     f32x4 t = sh[0][col];
 #pragma unroll
     for (int g = 1; g < 8; ++g) t += sh[g][col];
+    t *= scale;
     f32x4* o = reinterpret_cast<f32x4*>(out) + i4;
     *o = accumulate ? *o + t : t;
   }
@@ -839,7 +879,7 @@ __global__ void k_images(ImgArgs a) {
     const float wbwd = Wl[(long)(16 * s + pi_perm(h, j)) * WD + 32 * tile + r] * (l - 1 == 0 ? a.om_first : a.om_hidden);
     const long dst = ((long)(l - 1) * G.PIECES + G.tile_piece(tile) + s) * 512 + lane * 8 + j;
     a.wf[dst] = a.fwd_is_f16 ? to_f16(wfwd) : to_bf16(wfwd);
-    a.wb[gid] = to_bf16(wbwd);
+    a.wb[gid] = a.fwd_is_f16 ? to_f16(wbwd) : to_bf16(wbwd);
   }
   if (gid < (long)(a.depth - 2) * WD) {  // hidden biases into the bias pieces (fp32, pre-scaled)
     const int l = (int)(gid / WD) + 1, n = (int)(gid % WD), nt = n / 32;
@@ -871,7 +911,7 @@ __global__ void k_images(ImgArgs a) {
     float w = 0.f;
     if (c < a.out_features)
       w = a.params[a.off_w[L] + (long)c * WD + 32 * tile + r] * (L - 1 == 0 ? a.om_first : a.om_hidden);
-    a.wb_last[gid] = to_bf16(w);
+    a.wb_last[gid] = a.fwd_is_f16 ? to_f16(w) : to_bf16(w);
   }
   if (gid < WD) {
     const float* W0 = a.params + a.off_w[0];

@@ -6,10 +6,12 @@ separate "rounding" (engine == this model to ~1e-5) from "algorithm" (this model
 
   forward  hidden / last GEMM operands rounded to fp16 (weights pre-scaled by 2^8) or bf16, f32 accumulate;
            layer 0 in f32; sine computed on z*omega/(2 pi) revolutions;
-  spill    only the PHASE frac(z*omega/2pi) as unorm16 (x*65535, round-nearest-even);
-  backward all GEMM operands bf16: delta_l = bf16((delta W*omega) * cos(2 pi q/65536)), activations
-           re-derived as bf16(sin(2 pi q/65536)), backward weight image = bf16(W * omega_{l-1}); dL/dout = bf16(resid/(3N)); layer-0 coordinates
-           split x = bf16(x) + bf16(x - bf16(x)).
+  spill    only the PHASE frac(z*omega/2pi) of the HIDDEN layers as unorm16 (x*65535, round-nearest-even);
+           layer-0 phases are re-derived from the pixel coordinates in the backward (fp32, not quantised);
+  backward all GEMM operands in the same 16-bit type T as the forward (fp16 by default, deltas pre-scaled
+           by a power of two so they sit in fp16's normal range - modelled here as *2^20):
+           delta_l = T((delta W*omega) * cos(2 pi q/65536)), activations re-derived as T(sin(2 pi q/65536)),
+           backward weight image = T(W * omega_{l-1}); dL/dout = T(resid/(3N)); layer-0 coordinates split x = T(x) + T(x - T(x)).
 """
 import math
 from typing import Sequence
@@ -45,7 +47,8 @@ def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torc
     sc_first = torch.tensor(first_omega_0 / TWO_PI, dtype=torch.float32)
     sc_hidden = torch.tensor(hidden_omega_0 / TWO_PI / ws, dtype=torch.float32)
     t = z * sc_first
-    q = [_phase_q(t)]
+    ph0 = t - torch.floor(t)          # layer-0 phases are not spilled: k_bwd re-derives them from the coordinates
+    q = [None]
     a = torch.sin(TWO_PI * t.double()).float()
     for l in range(1, depth - 1):
         acc = _rt(a, fwd) @ _rt(params[2 * l] * ws, fwd).t() + params[2 * l + 1] * ws
@@ -58,19 +61,20 @@ def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torc
     resid = pred - img.reshape(n, -1)
     sse = float((resid.double() ** 2).sum())
     gscale = torch.tensor(1.0 / (3.0 * n), dtype=torch.float32)
-    delta = _rt(resid * gscale, "bf16")
+    bwd = fwd                      # the backward GEMM operands use the same 16-bit type as the forward
+    delta = _rt(resid * gscale, bwd) if bwd == "bf16" else _rt(resid * gscale * 2.0 ** 20, bwd) * 2.0 ** -20
     grads = [None] * (2 * depth)
     for l in range(L, 0, -1):
         # backward phase decode: u dropped into a float mantissa -> u/65536 revolutions (k_bwd phase_rev_*)
-        ph = q[l - 1] * (1.0 / 65536.0)
-        act = _rt(torch.sin(TWO_PI * ph.double()).float(), "bf16")
+        ph = ph0 if l - 1 == 0 else q[l - 1] * (1.0 / 65536.0)
+        act = _rt(torch.sin(TWO_PI * ph.double()).float(), bwd)
         grads[2 * l] = delta.t() @ act
         grads[2 * l + 1] = delta.sum(0)
         om = first_omega_0 if l - 1 == 0 else hidden_omega_0
-        G = delta @ _rt(params[2 * l] * om, "bf16")          # omega of layer l-1 is folded into the bf16 image
-        delta = _rt(G * torch.cos(TWO_PI * ph.double()).float(), "bf16")
-    xh = _rt(x, "bf16")
-    xl = _rt(x - xh, "bf16")
+        G = delta @ _rt(params[2 * l] * om, bwd)             # omega of layer l-1 is folded into the 16-bit image
+        delta = _rt(G * torch.cos(TWO_PI * ph.double()).float() * 2.0 ** 20, bwd) * 2.0 ** -20
+    xh = _rt(x, bwd)
+    xl = _rt(x - xh, bwd)
     grads[0] = delta.t() @ xh + delta.t() @ xl
     grads[1] = delta.sum(0)
     return sse / (3.0 * n), sse, grads, pred.reshape(h, w, -1)

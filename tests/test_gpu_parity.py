@@ -5,7 +5,8 @@ against golden vectors minted from the real reference.
 Tolerances (all stated where used):
   forward, fp16 operands   : |dpred| <= 3e-4 abs        (operand rounding 2^-11, f32 accumulate)
   forward, bf16 operands   : |dpred| <= 3e-3 abs        (2^-8)
-  gradients, bf16 backward : per-layer and total L2 error <= 1.5e-2 relative
+  gradients, fp16 operands : per-layer and total L2 error <= 5e-3 relative (measured ~1.3e-3)
+  gradients, bf16 operands : <= 3e-2 relative (measured ~9e-3; compute_dtype="bf16" option)
   PSNR after equal steps   : |dPSNR| <= 0.05 dB          (BASELINE.json north star)
   index / mask paths       : bit-exact
 """
@@ -35,8 +36,8 @@ def _engine(H, W, hidden, depth, dtype="f16", params=None, img=None, **kw):
 
 @pytest.mark.parametrize("name,hidden,depth", [("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8),
                                                ("grads_128x6_48", 128, 6)])
-@pytest.mark.parametrize("dtype,tol", [("f16", 3e-4), ("bf16", 3e-3)])
-def test_forward_and_gradients_vs_reference_golden(golden, name, hidden, depth, dtype, tol):
+@pytest.mark.parametrize("dtype,tol,gtol", [("f16", 3e-4, 5e-3), ("bf16", 3e-3, 3e-2)])
+def test_forward_and_gradients_vs_reference_golden(golden, name, hidden, depth, dtype, tol, gtol):
     d = golden(name)
     H, W, _ = d["img"].shape
     p = so.unflatten(d["init"], hidden, depth)
@@ -47,13 +48,13 @@ def test_forward_and_gradients_vs_reference_golden(golden, name, hidden, depth, 
     eng.forward_backward()
     g = eng.get_grads().cpu().numpy()
     ref = d["grads"]
-    assert np.linalg.norm(g - ref) <= 1.5e-2 * np.linalg.norm(ref)
+    assert np.linalg.norm(g - ref) <= gtol * np.linalg.norm(ref)
     off = 0
     for fin, fout in so.layer_dims(hidden, depth):
         for n in (fin * fout, fout):
             a, b = g[off:off + n], ref[off:off + n]
             off += n
-            assert np.linalg.norm(a - b) <= 1.5e-2 * np.linalg.norm(b)
+            assert np.linalg.norm(a - b) <= gtol * np.linalg.norm(b)
 
 
 @pytest.mark.parametrize("H,W,hidden,depth", [(5, 7, 32, 3), (1, 1, 64, 2), (17, 300, 64, 4), (33, 31, 128, 5)])
@@ -69,7 +70,7 @@ def test_ragged_and_tiny_grids(H, W, hidden, depth):
     assert abs(sse_e - sse) <= 2e-3 * sse
     eng.forward_backward()
     g, ref = eng.get_grads().cpu().numpy(), so.flatten(grads)
-    assert np.linalg.norm(g - ref) <= 1.5e-2 * np.linalg.norm(ref)
+    assert np.linalg.norm(g - ref) <= 5e-3 * np.linalg.norm(ref)
 
 
 def test_chunking_is_a_summation_order_change_only():
