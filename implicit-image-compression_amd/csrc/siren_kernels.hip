@@ -587,111 +587,118 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   //   X(k): delta_{k} B-pieces * stationary W^T -> G; epilogue: cos/sin of the phase piece this wave owns,
   //         delta_{l-1} to HBM, sin (bf16) written back IN PLACE over the phase piece
   //   W(k-1): dW += delta^T * act, both operands read transposed (ds_read_b64_tr_b16)
-  // ---- pieces of one pipeline step (block kx in phase X, block kx-1 in phase W) ------------------
-  // With one wave per SIMD nothing but this wave can fill the shadow of its own MFMAs, and hipcc emits
-  // MFMA chains and VALU epilogues back to back.  The step is therefore cut into CHUNKS of 4 MFMAs +
-  // a quarter of an epilogue, separated by sched_barrier(0): the in-order issue then places ~25 VALU
-  // instructions (about 100-130 cycles) behind every 4 asynchronous MFMAs (128 cycles of matrix pipe).
-  constexpr int XC = KSX >= 4 ? 4 : 1;          // chunks per X tile
-  constexpr int XS = KSX / XC;                  // k-steps per chunk
-  auto x_mma_chunk = [&](int k, int x, int c, f32x16& g) {
+  // ---- one pipeline step (block kx in phase X, block kx-1 in phase W), hand-scheduled ----------------
+  // One wave per SIMD: nothing but this wave can fill the shadow of its own MFMAs, and hipcc emits MFMA
+  // chains, LDS reads and VALU epilogues back to back.  The step is therefore written as a linear list of
+  // CHUNKS separated by sched_barrier(0); every chunk (a) issues the LDS reads of the NEXT chunk's operands
+  // into a second register set, (b) issues a few MFMAs on operands read one chunk earlier, (c) runs a slice
+  // of a VALU epilogue.  In-order issue then overlaps (b)'s matrix-pipe time with (a)'s latency and (c).
+  constexpr int XC = KSX >= 2 ? KSX / 2 : 1;    // X chunks per row tile
+  constexpr int XS = KSX / XC;                  // k-steps per X chunk (2, or 1 for the last layer)
+  constexpr int ESUB = 8;                       // epilogue slices per row tile: (q, j2) pairs of 2 values
+  auto x_load = [&](int k, int c, u32x4* dst) {
     const char* sD = smem + (k & (NB - 1)) * BLK;
 #pragma unroll
-    for (int s = c * XS; s < (c + 1) * XS; ++s) {
+    for (int i = 0; i < XS; ++i) dst[i] = reinterpret_cast<const u32x4*>(sD + (c * XS + i) * 1024)[lane];
+  };
+  auto x_mma_chunk = [&](int x, int c, const u32x4* b, f32x16& g) {
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int s = c * XS + i;
       const u32x4 w = s < KSR ? wreg[x][s < KSR ? s : 0]
                               : reinterpret_cast<const u32x4*>(sWsp + (x * WSP + (s >= KSR ? s - KSR : 0)) * 1024)[lane];
-      g = OP::mfma(w, reinterpret_cast<const u32x4*>(sD + s * 1024)[lane], g);
+      g = OP::mfma(w, b[i], g);
     }
   };
-  // quarter c of the epilogue of row tile x: c>>1 selects the phase piece (q), c&1 the half of its 8 values
+  // slice e of the epilogue of row tile x: e>>2 selects the phase piece (q), e&3 the pair of values
   u32x4 ep_p, ep_d, ep_s;
   float ep_x0 = 0.f, ep_x1 = 0.f;
-  auto x_epi_chunk = [&](int k, int x, int c, const f32x16& g) {
+  auto x_epi_sub = [&](int k, int x, int e, const f32x16& g) {
     char* sP = smem + (k & (NB - 1)) * BLK + KSJ * 1024;
-    const int q = c >> 1, hf = c & 1, ks = 2 * (xit0 + x) + q;
+    const int q = e >> 2, j2 = e & 3, ks = 2 * (xit0 + x) + q;
     u32x4* pp = reinterpret_cast<u32x4*>(sP + ks * 1024) + lane;
-    if (!P0 && hf == 0) ep_p = *pp;
-#pragma unroll
-    for (int j2 = 2 * hf; j2 < 2 * hf + 2; ++j2) {
-      float r0, r1;
-      if (P0) {   // phase of layer 0 from the coordinates: neurons 16*ks + PI(h, 2*j2), +1
-        const f32x4 t0 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2)], t1 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2 + 1)];
-        r0 = __builtin_fmaf(t0.y, ep_x1, __builtin_fmaf(t0.x, ep_x0, t0.z)) * a.sc_first;
-        r1 = __builtin_fmaf(t1.y, ep_x1, __builtin_fmaf(t1.x, ep_x0, t1.z)) * a.sc_first;
-      } else {
-        r0 = phase_rev_lo(ep_p[j2]); r1 = phase_rev_hi(ep_p[j2]);
-      }
-      ep_d[j2] = OP::pack2(g[8 * q + 2 * j2] * __builtin_amdgcn_cosf(r0),
-                               g[8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(r1));
-      ep_s[j2] = OP::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
+    if (!P0 && j2 == 0) ep_p = *pp;
+    float r0, r1;
+    if (P0) {   // phase of layer 0 from the coordinates: neurons 16*ks + PI(h, 2*j2), +1
+      const f32x4 t0 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2)], t1 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2 + 1)];
+      r0 = __builtin_fmaf(t0.y, ep_x1, __builtin_fmaf(t0.x, ep_x0, t0.z)) * a.sc_first;
+      r1 = __builtin_fmaf(t1.y, ep_x1, __builtin_fmaf(t1.x, ep_x0, t1.z)) * a.sc_first;
+    } else {
+      r0 = phase_rev_lo(ep_p[j2]); r1 = phase_rev_hi(ep_p[j2]);
     }
-    if (hf == 1) {
+    ep_d[j2] = OP::pack2(g[8 * q + 2 * j2] * __builtin_amdgcn_cosf(r0), g[8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(r1));
+    ep_s[j2] = OP::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
+    if (j2 == 3) {
       a.Dout[((pb_begin + k * pb_step) * KSI + ks) * 64 + lane] = ep_d;
       *pp = ep_s;
     }
   };
-  u32x4 fa[WJ], fb[WI];
-  auto w_load = [&](int k, int kk) {   // both operands of the dW product, read transposed from the ring slot
+  auto wa_load = [&](int k, int kk, int x) -> u32x4 {   // delta^T fragment (rows = neurons of this wave's tile x)
     const char* sD = smem + (k & (NB - 1)) * BLK;
-    const char* sP = sD + KSJ * 1024;
-#pragma unroll
-    for (int x = 0; x < WJ; ++x)
-      fa[x] = ds_read_tr_pair(sD, tr_addr(wr * WJ + x, kk, 0, lane), tr_addr(wr * WJ + x, kk, 1, lane));
+    return ds_read_tr_pair(sD, tr_addr(wr * WJ + x, kk, 0, lane), tr_addr(wr * WJ + x, kk, 1, lane));
+  };
+  auto wb_load = [&](int k, int kk, u32x4* dst) {       // activation fragments (cols = this wave's WI tiles)
+    const char* sP = smem + (k & (NB - 1)) * BLK + KSJ * 1024;
 #pragma unroll
     for (int y = 0; y < WI; ++y)
-      fb[y] = ds_read_tr_pair(sP, tr_addr(wc * WI + y, kk, 0, lane), tr_addr(wc * WI + y, kk, 1, lane));
+      dst[y] = ds_read_tr_pair(sP, tr_addr(wc * WI + y, kk, 0, lane), tr_addr(wc * WI + y, kk, 1, lane));
   };
-  auto w_mma_chunk = [&](int x) {
+  auto w_mma_chunk = [&](int x, const u32x4& fa, const u32x4* fb) {
 #pragma unroll
-    for (int y = 0; y < WI; ++y) acc[x][y] = OP::mfma(fa[x], fb[y], acc[x][y]);
-  };
-  auto db_chunk = [&](int x) {
+    for (int y = 0; y < WI; ++y) acc[x][y] = OP::mfma(fa, fb[y], acc[x][y]);
     if (wc == 0) {
       float tsum = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tsum += OP::sum2(fa[x][e]);
+      for (int e = 0; e < 4; ++e) tsum += OP::sum2(fa[e]);
       dbs[x] += tsum;
     }
   };
   auto step = [&](int kx, bool do_x, bool do_w) {
+    u32x4 xb[2][XS];            // X B-operand pieces, double-buffered
+    u32x4 fb[2][WI], fa[2];     // W operands: activation fragments per k-step (2 sets), delta^T fragment (2 sets)
     f32x16 gp = {}, gc = {};
     if (P0 && do_x) pixel_xy(kx, ep_x0, ep_x1);
+    if (do_x) x_load(kx, 0, xb[0]);
+    else if (do_w) { wb_load(kx - 1, 0, fb[0]); fa[0] = wa_load(kx - 1, 0, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- X chunks: tile x, chunk c; epilogue slices of tile x-1 ride along ----
     if (do_x) {
 #pragma unroll
-      for (int c = 0; c < XC; ++c) x_mma_chunk(kx, 0, c, gp);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int x = 1; x < XT; ++x) {
-      if (do_x) {
+      for (int x = 0; x < XT; ++x) {
         gc = f32x16{};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (c < XC) x_mma_chunk(kx, x, c, gc);
-          x_epi_chunk(kx, x - 1, c, gp);
+        for (int c = 0; c < XC; ++c) {
+          const int i = x * XC + c;                  // linear X chunk index; operands sit in xb[i & 1]
+          if (i + 1 < XT * XC) x_load(kx, (c + 1) % XC, xb[(i + 1) & 1]);
+          else if (do_w) { wb_load(kx - 1, 0, fb[0]); fa[0] = wa_load(kx - 1, 0, 0); }
+          x_mma_chunk(x, c, xb[i & 1], gc);
+          if (x > 0) {
+#pragma unroll
+            for (int e = c * ESUB / XC; e < (c + 1) * ESUB / XC; ++e) x_epi_sub(kx, x - 1, e, gp);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         gp = gc;
       }
     }
-    if (do_w) w_load(kx - 1, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    // ---- W chunks: k-step kk, row tile x; epilogue slices of the last X tile ride along in kk = 0 ----
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (do_w) {
+    for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int x = c * WJ / 4; x < (c + 1) * WJ / 4; ++x) { w_mma_chunk(x); db_chunk(x); }
+      for (int x = 0; x < WJ; ++x) {
+        const int i = kk * WJ + x;                    // linear W chunk index; delta^T fragment in fa[i & 1]
+        if (do_w) {
+          if (x + 1 < WJ) fa[(i + 1) & 1] = wa_load(kx - 1, kk, x + 1);
+          else if (kk == 0) { wb_load(kx - 1, 1, fb[1]); fa[(i + 1) & 1] = wa_load(kx - 1, 1, 0); }
+          w_mma_chunk(x, fa[i & 1], fb[kk]);
+        }
+        if (do_x && kk == 0) {
+#pragma unroll
+          for (int e = x * ESUB / WJ; e < (x + 1) * ESUB / WJ; ++e) x_epi_sub(kx, XT - 1, e, gp);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (do_x) x_epi_chunk(kx, XT - 1, c, gp);
-      __builtin_amdgcn_sched_barrier(0);
     }
-    if (do_w) {
-      w_load(kx - 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int x = 0; x < WJ; ++x) { w_mma_chunk(x); db_chunk(x); }
-    }
-    __builtin_amdgcn_sched_barrier(0);
   };
 
   if (nblk > 0) {
