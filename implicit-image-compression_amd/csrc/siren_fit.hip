@@ -191,7 +191,11 @@ int launch_bwd(sf_engine* h, bool last, bool p0, const BwdLayerArgs& a, int n_wg
     case 32: return last ? launch_bwd_t<32, 32, 1, 1, true>(h, a, n_wg, p0) : launch_bwd_t<32, 32, 1, 1, false>(h, a, n_wg, p0);
     case 64: return last ? launch_bwd_t<32, 64, 1, 2, true>(h, a, n_wg, p0) : launch_bwd_t<64, 64, 2, 1, false>(h, a, n_wg, p0);
     case 128: return last ? launch_bwd_t<32, 128, 1, 4, true>(h, a, n_wg, p0) : launch_bwd_t<128, 128, 2, 2, false>(h, a, n_wg, p0);
+#ifdef SF_EXPERIMENT_BWD8
+    case 256: return last ? launch_bwd_t<32, 256, 1, 8, true>(h, a, n_wg, p0) : launch_bwd_t<256, 256, 2, 4, false>(h, a, n_wg, p0);
+#else
     case 256: return last ? launch_bwd_t<32, 256, 1, 8, true>(h, a, n_wg, p0) : launch_bwd_t<256, 256, 2, 2, false>(h, a, n_wg, p0);
+#endif
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }

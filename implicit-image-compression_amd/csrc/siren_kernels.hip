@@ -69,6 +69,15 @@ struct OpF16 {
   }
 };
 
+// streaming store of one 16-byte piece element (scratch tensors are written once and read once much later)
+DEV void store_stream(u32x4* p, u32x4 v) {
+#ifdef SF_EXPERIMENT_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 DEV uint32_t pack_phase2(float f0, float f1) {  // two fractions in [0,1) -> two unorm16 (x*65535, RNE)
   return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_u16(f0, f1));
 }
@@ -109,6 +118,9 @@ DEV void bar_dma() {
 }
 
 DEV void glds16(const void* gsrc, char* lds_wave_base) {
+#ifdef SF_EXPERIMENT_NO_DMA    // timing-only build: no LDS-DMA traffic (kernels compute on stale LDS)
+  return;
+#endif
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
@@ -238,9 +250,9 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
       Bn[2 * nt + q] =
           u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]), OP::pack2(av[6], av[7])};
       if (TRAIN)
-        a.P[(size_t)l * a.p_stride + (pb * KS + 2 * nt + q) * 64 + lane] =
-            u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
-                  pack_phase2(ph[6], ph[7])};
+        store_stream(&a.P[(size_t)l * a.p_stride + (pb * KS + 2 * nt + q) * 64 + lane],
+                     u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
+                           pack_phase2(ph[6], ph[7])});
     }
   };
   // ---- hidden layers: [WD x WD] on MFMA, activations stay in registers ------------------------
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   // of a VALU epilogue.  In-order issue then overlaps (b)'s matrix-pipe time with (a)'s latency and (c).
   constexpr int XC = KSX >= 2 ? KSX / 2 : 1;    // X chunks per row tile
   constexpr int XS = KSX / XC;                  // k-steps per X chunk (2, or 1 for the last layer)
-  constexpr int ESUB = 8;                       // epilogue slices per row tile: (q, j2) pairs of 2 values
+  constexpr int ESUB = 4;                       // epilogue slices per row tile: (q, half) groups of 4 values
   auto x_load = [&](int k, int c, u32x4* dst) {
     const char* sD = smem + (k & (NB - 1)) * BLK;
 #pragma unroll
@@ -610,26 +622,34 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
       g = OP::mfma(w, b[i], g);
     }
   };
-  // slice e of the epilogue of row tile x: e>>2 selects the phase piece (q), e&3 the pair of values
+  // slice e of the epilogue of row tile x: e>>1 selects the phase piece (q), e&1 the half of its 8 values
+  // (4 independent cos/sin chains per slice keep the VALU fed while only one wave runs on the SIMD)
   u32x4 ep_p, ep_d, ep_s;
   float ep_x0 = 0.f, ep_x1 = 0.f;
   auto x_epi_sub = [&](int k, int x, int e, const f32x16& g) {
     char* sP = smem + (k & (NB - 1)) * BLK + KSJ * 1024;
-    const int q = e >> 2, j2 = e & 3, ks = 2 * (xit0 + x) + q;
+    const int q = e >> 1, hf = e & 1, ks = 2 * (xit0 + x) + q;
     u32x4* pp = reinterpret_cast<u32x4*>(sP + ks * 1024) + lane;
-    if (!P0 && j2 == 0) ep_p = *pp;
-    float r0, r1;
-    if (P0) {   // phase of layer 0 from the coordinates: neurons 16*ks + PI(h, 2*j2), +1
-      const f32x4 t0 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2)], t1 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2 + 1)];
-      r0 = __builtin_fmaf(t0.y, ep_x1, __builtin_fmaf(t0.x, ep_x0, t0.z)) * a.sc_first;
-      r1 = __builtin_fmaf(t1.y, ep_x1, __builtin_fmaf(t1.x, ep_x0, t1.z)) * a.sc_first;
-    } else {
-      r0 = phase_rev_lo(ep_p[j2]); r1 = phase_rev_hi(ep_p[j2]);
+    if (!P0 && hf == 0) ep_p = *pp;
+#pragma unroll
+    for (int j2 = 2 * hf; j2 < 2 * hf + 2; ++j2) {
+      float r0, r1;
+      if (P0) {   // phase of layer 0 from the coordinates: neurons 16*ks + PI(h, 2*j2), +1
+        const f32x4 t0 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2)], t1 = sL0[16 * ks + pi_perm(lane >> 5, 2 * j2 + 1)];
+        r0 = __builtin_fmaf(t0.y, ep_x1, __builtin_fmaf(t0.x, ep_x0, t0.z)) * a.sc_first;
+        r1 = __builtin_fmaf(t1.y, ep_x1, __builtin_fmaf(t1.x, ep_x0, t1.z)) * a.sc_first;
+      } else {
+        r0 = phase_rev_lo(ep_p[j2]); r1 = phase_rev_hi(ep_p[j2]);
+      }
+      ep_d[j2] = OP::pack2(g[8 * q + 2 * j2] * __builtin_amdgcn_cosf(r0), g[8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(r1));
+      ep_s[j2] = OP::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
     }
-    ep_d[j2] = OP::pack2(g[8 * q + 2 * j2] * __builtin_amdgcn_cosf(r0), g[8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(r1));
-    ep_s[j2] = OP::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
-    if (j2 == 3) {
-      a.Dout[((pb_begin + k * pb_step) * KSI + ks) * 64 + lane] = ep_d;
+    if (hf == 1) {
+#ifndef SF_EXPERIMENT_NO_STORE
+      store_stream(&a.Dout[((pb_begin + k * pb_step) * KSI + ks) * 64 + lane], ep_d);
+#else
+      asm volatile("" ::"v"(ep_d));
+#endif
       *pp = ep_s;
     }
   };
@@ -672,7 +692,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
           if (i + 1 < XT * XC) x_load(kx, (c + 1) % XC, xb[(i + 1) & 1]);
           else if (do_w) { wb_load(kx - 1, 0, fb[0]); fa[0] = wa_load(kx - 1, 0, 0); }
           x_mma_chunk(x, c, xb[i & 1], gc);
-          if (x > 0) {
+          if (x > 0) {   // ESUB slices of the previous tile spread over the XC chunks of this one
 #pragma unroll
             for (int e = c * ESUB / XC; e < (c + 1) * ESUB / XC; ++e) x_epi_sub(kx, x - 1, e, gp);
           }
