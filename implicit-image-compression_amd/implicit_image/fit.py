@@ -21,6 +21,8 @@ from .config import Cfg, expand_sweeps, load_config
 from .data import get_grid, load_img
 from .models import registry as model_registry
 from .parallel import shard_jobs
+from .pipeline import entropy_coding
+from .pipeline.quant import Quantize
 from .utils.train_helper import eval_epoch, get_device, get_optimizer_lr_scheduler, setup_mask, train_epoch
 
 REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
@@ -59,10 +61,36 @@ def fit_one(cfg: Cfg, device: torch.device, out_dir: str = None):
                 msg += f" | Prune Rate: {mask.prune_rate:.4f} | Density: {mask.stats.total_density:.4f}"
             logging.info(msg)
     last.update(steps=num_steps, seconds=time.time() - t0)
+    quantized_model = None
+    if cfg.get("quant"):                                                           # compress.py:172-240
+        qcfg = copy.deepcopy(cfg.quant)
+        depth = cfg.mlp.depth
+        qcfg.skip_ll = [s.replace("layers.first.", "layers.0.").replace("layers.last.", f"layers.{depth - 1}.")
+                        for s in (qcfg.get("skip_ll") or [])]
+        quantized_model = copy.deepcopy(model)
+        q_optim, q_sched = get_optimizer_lr_scheduler(quantized_model, cfg.optim, quantize_mode=True)
+        # NOTE: the reference passes the ORIGINAL model's mask here, which makes the quant phase step the
+        # wrong optimiser; this entry fine-tunes the copy without the mask.
+        with Quantize(quantized_model, q_optim, qcfg) as q:
+            for i in range(qcfg.num_steps):
+                train_epoch(quantized_model, q_optim, grid, img, lr_scheduler=q_sched)
+                if (i + 1) % qcfg.log_steps == 0:
+                    _, l, p, p8 = eval_epoch(quantized_model, grid, img)
+                    logging.info(f"Quant | Step: {i + 1} | loss: {l:.4f} | PSNR: {p:.4f} | PSNR_8bit: {p8:.4f}")
+        quantized_model = q.convert()
+        _, l, p, p8 = eval_epoch(quantized_model, grid, img)
+        last.update({"Quant loss": l, "Quant PSNR": p, "Quant PSNR 8bit": p8})
+        logging.info(f"Post Quant | Train step: {num_steps} | Quant step: {qcfg.num_steps} | Quant PSNR: {p:.4f}")
     if out_dir and cfg.train.save_weights:
         os.makedirs(out_dir, exist_ok=True)
         torch.save({"state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}},
                    os.path.join(out_dir, "model.pth"))                            # compress.py:243-244
+        if quantized_model is not None and cfg.get("entropy_coding"):              # compress.py:249-263
+            ec = dict(cfg.entropy_coding)
+            nbytes = entropy_coding.compress_state_dict(quantized_model.half(), os.path.join(out_dir, "model_quantized"),
+                                                        **ec)
+            last["Compressed Bytes"] = nbytes
+            logging.info(f"Compressed bytes {nbytes}")
         with open(os.path.join(out_dir, "result.json"), "w") as f:
             json.dump(last, f)
     return last

@@ -58,6 +58,10 @@ class Siren(nn.Module):
                         first_omega_0=float(first_omega_0), hidden_omega_0=float(hidden_omega_0),
                         outermost_linear=bool(outermost_linear), compute_dtype=compute_dtype,
                         chunk_pixels=chunk_pixels)
+        # callbacks run right before every engine pass / right after every backward: the seam the reference
+        # fills with per-Linear forward-pre and backward hooks (k-means quantisation, pipeline/quant/kmeans.py:39-55)
+        self.pre_pass_callbacks = []
+        self.post_backward_callbacks = []
         self._engine = None
         self._engine_key = None
         self._grid_key = None
@@ -98,6 +102,8 @@ class Siren(nn.Module):
             if self._target_key != tkey:
                 eng.set_target(img.contiguous().float())
                 self._target_key = tkey
+        for cb in list(self.pre_pass_callbacks):
+            cb()
         self._sync_to_engine()
         return eng
 
@@ -137,6 +143,12 @@ class Siren(nn.Module):
                 a.copy_(b)
         new.train(self.training)
         return new
+
+    def half(self):
+        """model.half() of the reference's save path (compress.py:246-250): detaches from the engine."""
+        if self._engine is not None:
+            self._unbind()
+        return super().half()
 
     # ---- reference call signature -----------------------------------------------------------
     def forward(self, grid: torch.Tensor) -> torch.Tensor:

@@ -125,6 +125,8 @@ def train_epoch(model: Module, optim: Optimizer, grid, img, **kwargs) -> float:
     eng = model.engine(grid, img)
     sse = eng.forward_backward(sync=True)
     loss = sse / (img.shape[0] * img.shape[1] * img.shape[2])
+    for cb in list(getattr(model, "post_backward_callbacks", ())):
+        cb()
     if mask:
         mask.step(kwargs.get("scaler"))
     else:

@@ -326,3 +326,25 @@ def test_make_fit_entry_runs_the_reference_loop(tmp_path, monkeypatch):
     assert abs(res["PSNR"] - psnr_ref) <= 0.05
     sd = torch.load(tmp_path / "out" / "model.pth", weights_only=True)["state_dict"]
     assert list(sd)[:2] == ["layers.0.linear.weight", "layers.0.linear.bias"]
+
+
+def test_make_fit_quant_and_compress_tail(tmp_path, monkeypatch):
+    """compress.py:172-263 on the engine: k-means (8 bit) fine-tune, convert, half(), plain container;
+    the container decodes back to the codebook weights and the quantised model keeps the PSNR."""
+    import os
+    from implicit_image.config import load_config
+    from implicit_image.fit import fit_one
+    from implicit_image.pipeline import entropy_coding
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(tmp_path)
+    cfg = load_config(os.path.join(root, "conf"), ["img.height=64", "img.width=64", "mlp.hidden_size=64", "mlp.depth=4",
+                                                   "train.num_steps=300", "train.log_steps=300", "quant=kmeans",
+                                                   "quant.num_steps=10", "quant.log_steps=10"])
+    res = fit_one(cfg, torch.device("cuda", 0), str(tmp_path / "out"))
+    assert res["Quant PSNR"] > res["PSNR"] - 1.0                 # 8-bit codebook costs well under 1 dB here
+    meta_dir = tmp_path / "out" / "model_quantized"
+    dec = entropy_coding.decompress_state_dict(meta_dir, "plain")
+    assert set(dec) == {f"layers.{i}.linear.{k}" for i in range(4) for k in ("weight", "bias")}
+    assert res["Compressed Bytes"] == os.path.getsize(meta_dir / "compressed_weights.data")
+    # 2 quantised 64x64 layers: 4096 one-byte labels each instead of 8192 bytes of fp16
+    assert res["Compressed Bytes"] < 2 * (64 * 64 * 1 + 256 * 2) + (64 * 2 + 64 + 3 * 64 + 3 + 128) * 2 + 64
