@@ -69,7 +69,12 @@ class Siren(nn.Module):
 
     # ---- engine binding -------------------------------------------------------------------
     def _param_list(self):
-        return list(self.parameters())
+        """The engine's parameters in flat order: (weight, bias) of every layer.  Not `self.parameters()`:
+        k-means conversion registers extra (frozen) `centroids` / `labeled_weight` parameters on the Linears."""
+        out = []
+        for layer in self.layers:
+            out += [layer.linear.weight, layer.linear.bias]
+        return out
 
     def engine(self, grid: torch.Tensor, img: Optional[torch.Tensor] = None, row_begin: int = 0, row_end: int = 0,
                full_height: Optional[int] = None):
@@ -139,7 +144,7 @@ class Siren(nn.Module):
                     chunk_pixels=c["chunk_pixels"])
         new.to(next(self.parameters()).device)
         with torch.no_grad():
-            for a, b in zip(new.parameters(), self.parameters()):
+            for a, b in zip(new._param_list(), self._param_list()):
                 a.copy_(b)
         new.train(self.training)
         return new

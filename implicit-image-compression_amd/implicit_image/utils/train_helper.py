@@ -35,7 +35,7 @@ class EngineAdam(Optimizer):
         if tuple(betas) != (0.9, 0.999) or eps != 1e-8:
             raise NotImplementedError("EngineAdam uses torch.optim.Adam's default betas/eps (conf/optim/adam.yaml)")
         self.model = model
-        super().__init__(model.parameters(), dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+        super().__init__(model._param_list(), dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self._bound = None
 
     def _bind_state(self, eng):
@@ -43,7 +43,7 @@ class EngineAdam(Optimizer):
             return
         m, v = eng.view("exp_avg"), eng.view("exp_avg_sq")
         off = 0
-        for p in self.model.parameters():
+        for p in self.model._param_list():
             n = p.numel()
             st = self.state[p]
             st["step"] = torch.tensor(0.0)
@@ -62,7 +62,7 @@ class EngineAdam(Optimizer):
             raise RuntimeError("EngineAdam.step() before any forward/backward: the engine is created by train_epoch")
         self._bind_state(eng)
         eng.adam_step(float(self.param_groups[0]["lr"]))
-        for p in self.model.parameters():
+        for p in self.model._param_list():
             self.state[p]["step"] += 1
         return None
 
