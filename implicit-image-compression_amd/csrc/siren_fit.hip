@@ -1,8 +1,8 @@
 // siren_fit.hip — C ABI (include/siren_fit.h) and host-side orchestration of the gfx950 kernels.
 //
 // One sf_engine == one per-image fit on one HIP stream.  A training step is, per pixel chunk:
-//   k_fwd -> k_bwdx -> k_dw(last) -> k_dw(hidden l = depth-2 .. 1) -> k_dw(first), each k_dw followed by
-//   k_reduce into the flat fp32 gradient; then k_adam (+mask) and k_images (16-bit weight images).
+//   k_fwd -> k_bwd(last) -> k_bwd(hidden l = depth-2 .. 1) -> k_dw0, each followed by the fixed-order slab
+//   reduction into the flat fp32 gradient; then k_adam (+mask) and k_images (16-bit weight images).
 // The sequence mirrors one `train_epoch` of the reference (implicit_image/utils/train_helper.py:132-185)
 // for the full-batch grid (implicit_image/compress.py:137-138).
 #include "siren_kernels.hip"
@@ -146,67 +146,64 @@ int launch_fwd_t(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
   return SF_OK;
 }
 
-template <int ROWS, int COLS, int WR, int WC, int BSRC, typename OP>
-int launch_dw_to(sf_engine* h, const DwArgs& a, int n_wg) {
-  const size_t lds = (size_t)2 * (ROWS / 16 + COLS / 16) * 1024;
-  int rc = set_lds(k_dw<ROWS, COLS, WR, WC, BSRC, OP>, lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL((k_dw<ROWS, COLS, WR, WC, BSRC, OP>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
-  HIPCHK(hipGetLastError());
-  return SF_OK;
-}
-template <int ROWS, int COLS, int WR, int WC, int BSRC>
-int launch_dw_t(sf_engine* h, const DwArgs& a, int n_wg) {
-  return h->cfg.compute_dtype == SF_F16 ? launch_dw_to<ROWS, COLS, WR, WC, BSRC, OpF16>(h, a, n_wg)
-                                        : launch_dw_to<ROWS, COLS, WR, WC, BSRC, OpBF16>(h, a, n_wg);
-}
-
-template <int JW, int IW, int WR, int WC, bool LAST, bool P0, typename OP>
-int launch_bwd_tpo(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
-  // 4-slot block ring + (widest configuration only) the parked part of the stationary weight rows
+template <int JW, int IW, int WR, int WC, bool LAST, bool P0, typename OP, int NB>
+int launch_bwd_k(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
+  // NB-slot block ring + (when the stationary weight rows do not fit in registers) their parked part
   // + (P0) the layer-0 table
   constexpr int NWV = WR * WC, XT = (IW / 32) / NWV, KSX = LAST ? 1 : JW / 16;
   constexpr int WSP = (XT * KSX > 24) ? (P0 ? 3 : 4) : 0;
-  const size_t lds = (size_t)4 * (JW / 16 + IW / 16) * 1024 + (size_t)NWV * XT * WSP * 1024 + (P0 ? (size_t)IW * 16 : 0);
-  int rc = set_lds(k_bwd<JW, IW, WR, WC, LAST, P0, OP>, lds);
+  const size_t lds = (size_t)NB * (JW / 16 + IW / 16) * 1024 + (size_t)NWV * XT * WSP * 1024 + (P0 ? (size_t)IW * 16 : 0);
+  int rc = set_lds(k_bwd<JW, IW, WR, WC, LAST, P0, OP, NB>, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_bwd<JW, IW, WR, WC, LAST, P0, OP>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
+  hipLaunchKernelGGL((k_bwd<JW, IW, WR, WC, LAST, P0, OP, NB>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
   HIPCHK(hipGetLastError());
   return SF_OK;
 }
-template <int JW, int IW, int WR, int WC, bool LAST, bool P0>
+template <int JW, int IW, int WR, int WC, bool LAST, bool P0, int NB>
 int launch_bwd_tp(sf_engine* h, const BwdLayerArgs& a, int n_wg) {
-  return h->cfg.compute_dtype == SF_F16 ? launch_bwd_tpo<JW, IW, WR, WC, LAST, P0, OpF16>(h, a, n_wg)
-                                        : launch_bwd_tpo<JW, IW, WR, WC, LAST, P0, OpBF16>(h, a, n_wg);
+  return h->cfg.compute_dtype == SF_F16 ? launch_bwd_k<JW, IW, WR, WC, LAST, P0, OpF16, NB>(h, a, n_wg)
+                                        : launch_bwd_k<JW, IW, WR, WC, LAST, P0, OpBF16, NB>(h, a, n_wg);
 }
-template <int JW, int IW, int WR, int WC, bool LAST>
+template <int JW, int IW, int WR, int WC, bool LAST, int NB>
 int launch_bwd_t(sf_engine* h, const BwdLayerArgs& a, int n_wg, bool p0) {
-  return p0 ? launch_bwd_tp<JW, IW, WR, WC, LAST, true>(h, a, n_wg) : launch_bwd_tp<JW, IW, WR, WC, LAST, false>(h, a, n_wg);
+  return p0 ? launch_bwd_tp<JW, IW, WR, WC, LAST, true, NB>(h, a, n_wg) : launch_bwd_tp<JW, IW, WR, WC, LAST, false, NB>(h, a, n_wg);
 }
 
 // fused backward of one layer: last = the out_features(<=3, padded to 32)-row layer; p0 = its input layer is
-// layer 0, whose phases are re-derived from the coordinates
+// layer 0, whose phases are re-derived from the coordinates.  Ring depths are chosen to fill the 160 KiB of LDS.
 int launch_bwd(sf_engine* h, bool last, bool p0, const BwdLayerArgs& a, int n_wg) {
   switch (h->WD) {
-    case 32: return last ? launch_bwd_t<32, 32, 1, 1, true>(h, a, n_wg, p0) : launch_bwd_t<32, 32, 1, 1, false>(h, a, n_wg, p0);
-    case 64: return last ? launch_bwd_t<32, 64, 1, 2, true>(h, a, n_wg, p0) : launch_bwd_t<64, 64, 2, 1, false>(h, a, n_wg, p0);
-    case 128: return last ? launch_bwd_t<32, 128, 1, 4, true>(h, a, n_wg, p0) : launch_bwd_t<128, 128, 2, 2, false>(h, a, n_wg, p0);
-#ifdef SF_EXPERIMENT_BWD8
-    case 256: return last ? launch_bwd_t<32, 256, 1, 8, true>(h, a, n_wg, p0) : launch_bwd_t<256, 256, 2, 4, false>(h, a, n_wg, p0);
-#else
-    case 256: return last ? launch_bwd_t<32, 256, 1, 8, true>(h, a, n_wg, p0) : launch_bwd_t<256, 256, 2, 2, false>(h, a, n_wg, p0);
-#endif
+    case 32: return last ? launch_bwd_t<32, 32, 1, 1, true, 8>(h, a, n_wg, p0) : launch_bwd_t<32, 32, 1, 1, false, 8>(h, a, n_wg, p0);
+    case 64: return last ? launch_bwd_t<32, 64, 1, 2, true, 8>(h, a, n_wg, p0) : launch_bwd_t<64, 64, 2, 1, false, 8>(h, a, n_wg, p0);
+    case 128: return last ? launch_bwd_t<32, 128, 1, 4, true, 8>(h, a, n_wg, p0) : launch_bwd_t<128, 128, 2, 2, false, 8>(h, a, n_wg, p0);
+    case 256:
+      if (last) return launch_bwd_t<32, 256, 1, 8, true, 8>(h, a, n_wg, p0);
+      // 8 waves (two per SIMD), all weight rows in registers, 5 x 32 KiB ring = 160 KiB: 96 KiB in flight;
+      // the P0 variant needs more registers and keeps the 4-wave / 4-slot form
+      return p0 ? launch_bwd_tp<256, 256, 2, 2, false, true, 4>(h, a, n_wg)
+                : launch_bwd_tp<256, 256, 2, 4, false, false, 5>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
 
 // weight gradient of layer 0 (no data gradient needed): contraction of delta_0 with the coordinates
-int launch_dw_first(sf_engine* h, const DwArgs& a, int n_wg) {
+template <int JW>
+int launch_dw0_t(sf_engine* h, const Dw0Args& a, int n_wg) {
+  const size_t lds = (size_t)8 * (JW / 16) * 1024 + 512;   // ring + coordinate table
+  const bool f16 = h->cfg.compute_dtype == SF_F16;
+  int rc = f16 ? set_lds(k_dw0<JW, OpF16>, lds) : set_lds(k_dw0<JW, OpBF16>, lds);
+  if (rc) return rc;
+  if (f16) hipLaunchKernelGGL((k_dw0<JW, OpF16>), dim3(n_wg), dim3(JW * 2), lds, h->stream, a);
+  else hipLaunchKernelGGL((k_dw0<JW, OpBF16>), dim3(n_wg), dim3(JW * 2), lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+int launch_dw_first(sf_engine* h, const Dw0Args& a, int n_wg) {
   switch (h->WD) {
-    case 32: return launch_dw_t<32, 32, 1, 1, 1>(h, a, n_wg);
-    case 64: return launch_dw_t<64, 32, 2, 1, 1>(h, a, n_wg);
-    case 128: return launch_dw_t<128, 32, 4, 1, 1>(h, a, n_wg);
-    case 256: return launch_dw_t<256, 32, 8, 1, 1>(h, a, n_wg);
+    case 32: return launch_dw0_t<32>(h, a, n_wg);
+    case 64: return launch_dw0_t<64>(h, a, n_wg);
+    case 128: return launch_dw0_t<128>(h, a, n_wg);
+    case 256: return launch_dw0_t<256>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
@@ -337,15 +334,19 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         ra.slab_rows = last ? 32 : WD; ra.slab_cols = WD;
         ra.rows_out = last ? h->cfg.out_features : WD; ra.cols_out = WD; ra.mode = 0;
       } else {
-        DwArgs da;
+        Dw0Args da;
         memset(&da, 0, sizeof(da));
-        da.gh = h->gh; da.gw = h->gw; da.W = h->cfg.width; da.row_begin = h->cfg.row_begin;
-        da.pix0 = pix0; da.npix = h->npix; da.n_pb = n_pb; da.pb_per_wg = (int)pb_per_wg; da.slab = h->slab;
-        da.A = h->Dbuf;
+        da.D = h->Dbuf; da.n_pb = n_pb; da.slab = h->slab; da.pix0 = pix0; da.npix = h->npix;
+        da.W = h->cfg.width; da.row_begin = h->cfg.row_begin;
+        da.inv_hm1 = h->cfg.height > 1 ? 1.0f / (float)(h->cfg.height - 1) : 0.f;
+        da.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
+        da.w_magic = ((1ULL << 40) + (unsigned long long)h->cfg.width - 1) / (unsigned long long)h->cfg.width;
         Launch L(h, K_DW_FIRST, 4.0 * WD * n_pb * 32.0, WD * 2.0 * n_pb * 32.0);
-        rc = launch_dw_first(h, da, n_wg);
+        int n_wg0 = (int)(n_pb < (long)h->dw_wg ? n_pb : (long)h->dw_wg);
+        rc = launch_dw_first(h, da, n_wg0);
         L.done();
         if (rc) return rc;
+        ra.n_wg = n_wg0;
         ra.slab_rows = WD; ra.slab_cols = 32; ra.rows_out = WD; ra.cols_out = 2; ra.mode = 1;
       }
       {

@@ -10,9 +10,10 @@
 //   k_fwd      fused forward chain: coords -> layer 0 (f32 VALU) -> hidden layers on MFMA with the
 //              activations resident in registers (accumulator-as-next-B-operand) -> last layer ->
 //              residual, SSE partial, dL/dout; spills only the 16-bit PHASE of every sine (F-layout).
-//   k_bwdx     fused backward-data chain: delta_l -> delta_{l-1} on MFMA, cos recomputed from the phase.
-//   k_dw       weight-gradient GEMM per layer, contraction over pixels: dW_l = delta_l^T * sin(phase_{l-1}),
-//              operands staged in LDS and read with ds_read_b64_tr_b16, persistent 256x256 accumulators.
+//   k_bwd      one layer of the backward pass: data gradient (delta_l -> delta_{l-1}, cos re-derived from the
+//              phase) fused with the weight gradient dW_l = delta_l^T * sin(phase_{l-1}) (contraction over
+//              pixels, operands read with ds_read_b64_tr_b16 from a DMA-fed LDS ring, 256x256 accumulators).
+//   k_dw0      weight gradient of layer 0 against the coordinates.
 //   k_reduce   fixed-order reduction of the per-workgroup dW slabs into the flat gradient.
 //   k_adam     Adam + mask (torch.optim.Adam op order), k_images: rebuild the 16-bit weight images.
 #include <hip/hip_runtime.h>
@@ -334,26 +335,8 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_dw: dW[j][i] = sum_pixels delta[pix][j] * act[pix][i],  db[j] = sum_pixels delta[pix][j]
-//   A source: delta image (F-layout, KSA = rows/16 k-steps per block), rows = output neurons j
-//   B source: BSRC 0: phase image of the previous layer (F-layout) -> sin -> bf16
-//             BSRC 1: the two coordinates (layer 0): columns {x0_hi, x0_lo, x1_hi, x1_lo, 0...}
-//                     (hi + lo bf16 split keeps 16 significant bits of the coordinate)
-//   Each workgroup sweeps a contiguous range of pixel blocks and keeps its ROWS x COLS accumulator in
-//   registers; the per-workgroup result goes to a slab that k_reduce sums in a fixed order.
+// transposed LDS reads of F-layout blocks (operands of the pixel-contraction products)
 // ---------------------------------------------------------------------------------------------
-struct DwArgs {
-  const u32x4* A;      // delta image
-  const u32x4* Bp;     // phase image (BSRC 0)
-  const float* gh;     // coords (BSRC 1)
-  const float* gw;
-  int W, row_begin;
-  long pix0, npix;
-  long n_pb;           // pixel blocks (of 32) in this chunk
-  int pb_per_wg;       // blocks per workgroup (multiple of PBS)
-  float* slab;         // [gridDim.x][ROWS*COLS + ROWS]
-};
-
 // address (in bytes, relative to an F-layout block of KS k-steps) that lane must supply to
 // ds_read_b64_tr_b16 for fragment tile `tile` (32 neurons), pixel k-step kk (16 pixels), half-read u.
 // Returned fragment: lane (r = lane&31 -> neuron 32*tile + r, hq = lane>>5), elements = pixels
@@ -371,125 +354,6 @@ DEV u32x4 ds_read_tr_pair(const char* base, int off0, int off1) {
   const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
   const u32x2 a0 = __builtin_bit_cast(u32x2, r0), a1 = __builtin_bit_cast(u32x2, r1);
   return u32x4{a0.x, a0.y, a1.x, a1.y};
-}
-
-template <int ROWS, int COLS, int WAVES_R, int WAVES_C, int BSRC, typename OP>
-__global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_dw(DwArgs a) {
-  constexpr int NW = WAVES_R * WAVES_C, NTHR = NW * 64;
-  constexpr int JT = ROWS / 32, IT = COLS / 32;
-  constexpr int WJ = JT / WAVES_R, WI = IT / WAVES_C;   // tiles per wave
-  constexpr int KSA = ROWS / 16, KSB = COLS / 16;
-  constexpr int PBS = 2;                                 // pixel blocks staged per iteration (64 px)
-  static_assert(JT % WAVES_R == 0 && IT % WAVES_C == 0, "tiling");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;                                       // PBS*KSA*1024
-  char* sB = smem + PBS * KSA * 1024;                    // PBS*KSB*1024
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wr = wave / WAVES_C, wc = wave % WAVES_C;
-
-  f32x16 acc[WJ][WI];
-#pragma unroll
-  for (int x = 0; x < WJ; ++x)
-#pragma unroll
-    for (int y = 0; y < WI; ++y) acc[x][y] = f32x16{};
-  float dbs[WJ];
-#pragma unroll
-  for (int x = 0; x < WJ; ++x) dbs[x] = 0.f;
-
-  const long pb_begin = (long)blockIdx.x * a.pb_per_wg;
-  long pb_end = pb_begin + a.pb_per_wg;
-  if (pb_end > a.n_pb) pb_end = a.n_pb;
-
-  for (long pb = pb_begin; pb < pb_end; pb += PBS) {
-    __syncthreads();
-    // ---- stage A (deltas): straight copy of PBS*KSA pieces ----
-    for (int i = tid; i < PBS * KSA * 64; i += NTHR) {
-      const long blk = pb + i / (KSA * 64);
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (blk < pb_end) v = a.A[pb * KSA * 64 + i];
-      reinterpret_cast<u32x4*>(sA)[i] = v;
-    }
-    // ---- stage B ----
-    if (BSRC == 0) {
-      for (int i = tid; i < PBS * KSB * 64; i += NTHR) {
-        const long blk = pb + i / (KSB * 64);
-        u32x4 o = u32x4{0u, 0u, 0u, 0u};
-        if (blk < pb_end) {
-          const u32x4 p = a.Bp[pb * KSB * 64 + i];
-#pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2) {
-            const float s0 = __builtin_amdgcn_sinf((float)(p[j2] & 0xffffu) * kInv65535);
-            const float s1 = __builtin_amdgcn_sinf((float)(p[j2] >> 16) * kInv65535);
-            o[j2] = OP::pack2(s0, s1);
-          }
-        }
-        reinterpret_cast<u32x4*>(sB)[i] = o;
-      }
-    } else {
-      // one 32-neuron tile (2 k-steps): k-step 0, h=0, j=0..3 -> columns 0..3 = x0_hi,x0_lo,x1_hi,x1_lo
-      for (int i = tid; i < PBS * KSB * 64; i += NTHR) {
-        const int bi = i / (KSB * 64), r = i % (KSB * 64), s = r / 64, ln = r % 64;
-        u32x4 o = u32x4{0u, 0u, 0u, 0u};
-        if (s == 0 && ln < 32 && pb + bi < pb_end) {
-          long pix = a.pix0 + (pb + bi) * 32 + ln;
-          if (pix >= a.npix) pix = a.npix - 1;
-          const int row = (int)(pix / a.W), col = (int)(pix - (long)row * a.W);
-          const float x0 = (a.gh[a.row_begin + row] - 0.5f) * 2.0f, x1 = (a.gw[col] - 0.5f) * 2.0f;
-          const float x0h = OP::lo(OP::pack2(x0, 0.f)), x1h = OP::lo(OP::pack2(x1, 0.f));
-          o[0] = OP::pack2(x0h, x0 - x0h);
-          o[1] = OP::pack2(x1h, x1 - x1h);
-        }
-        reinterpret_cast<u32x4*>(sB)[i] = o;
-      }
-    }
-    __syncthreads();
-    // ---- MFMA over the staged pixels: k-steps of 16 pixels ----
-#pragma unroll
-    for (int bi = 0; bi < PBS; ++bi) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        u32x4 fa[WJ], fb[WI];
-#pragma unroll
-        for (int x = 0; x < WJ; ++x)
-          fa[x] = ds_read_tr_pair(sA + bi * KSA * 1024, tr_addr(wr * WJ + x, kk, 0, lane),
-                                  tr_addr(wr * WJ + x, kk, 1, lane));
-#pragma unroll
-        for (int y = 0; y < WI; ++y)
-          fb[y] = ds_read_tr_pair(sB + bi * KSB * 1024, tr_addr(wc * WI + y, kk, 0, lane),
-                                  tr_addr(wc * WI + y, kk, 1, lane));
-#pragma unroll
-        for (int x = 0; x < WJ; ++x)
-#pragma unroll
-          for (int y = 0; y < WI; ++y) acc[x][y] = OP::mfma(fa[x], fb[y], acc[x][y]);
-        if (wc == 0) {
-#pragma unroll
-          for (int x = 0; x < WJ; ++x) {
-            float t = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t += OP::sum2(fa[x][e]);
-            dbs[x] += t;
-          }
-        }
-      }
-    }
-  }
-  // ---- write the slab: dW tile (jt, it): lane col = lane&31, reg t row = rho(t, lane>>5) ----
-  float* slab = a.slab + (size_t)blockIdx.x * (ROWS * COLS + ROWS);
-  const int cl = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int x = 0; x < WJ; ++x)
-#pragma unroll
-    for (int y = 0; y < WI; ++y)
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-        slab[(size_t)(32 * (wr * WJ + x) + rho(t, hh)) * COLS + 32 * (wc * WI + y) + cl] = acc[x][y][t];
-  if (wc == 0) {
-#pragma unroll
-    for (int x = 0; x < WJ; ++x) {
-      const float t = dbs[x] + __shfl_xor(dbs[x], 32);
-      if (hh == 0) slab[ROWS * COLS + 32 * (wr * WJ + x) + cl] = t;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -522,7 +386,7 @@ struct BwdLayerArgs {
   float sc_first;               // first_omega_0 / (2 pi)
 };
 
-template <int JW, int IW, int WAVES_R, int WAVES_C, bool LAST, bool P0, typename OP>
+template <int JW, int IW, int WAVES_R, int WAVES_C, bool LAST, bool P0, typename OP, int NB>
 __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   constexpr int NW = WAVES_R * WAVES_C;
   constexpr int JT = JW / 32, IT = IW / 32;
@@ -531,7 +395,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   constexpr int KSX = LAST ? 1 : KSJ;         // k-steps of the dX product (last layer: <= 3 real rows -> one step)
   constexpr int XT = IT / NW;                 // phase-X row tiles per wave
   static_assert(IT % NW == 0, "phase-X tiling needs NW <= IT");
-  constexpr int NB = 4;                       // LDS ring: blocks of 32 pixels
+  // NB = LDS ring depth in blocks of 32 pixels.  Block k is requested PD = NB-2 steps before it is used: the
+  // loaded HBM latency is several microseconds, so the bytes in flight per CU (PD * BLK) set the streaming
+  // rate long before the instruction schedule does (measured: 2 blocks in flight = 10 GB/s per CU).
+  constexpr int PD = NB - 2;
   constexpr int BLK = (KSJ + KSI) * 1024;     // bytes per ring slot: delta pieces then phase pieces
   constexpr int G_MIN = KSJ / NW + (P0 ? 0 : KSI / NW);  // LDS-DMA instructions every wave issues per block (lower bound)
   constexpr int S_ST = 2 * XT;                // delta stores per wave per block
@@ -571,7 +438,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   const int nblk = (int)((a.n_pb - pb_begin + pb_step - 1) / pb_step);
 
   auto stage = [&](int k) {   // block k of this workgroup -> ring slot k % NB, one 1 KiB piece per wave-instruction
-    char* base = smem + (k & (NB - 1)) * BLK;
+    char* base = smem + (k % NB) * BLK;
     const long pb = pb_begin + k * pb_step;
     for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * KSJ + pc) * 64 + lane, base + pc * 1024);
     if (!P0)
@@ -592,12 +459,11 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
     x1 = ((float)col * a.inv_wm1 - 0.5f) * 2.0f;
   };
 
-  if (nblk > 0) stage(0);
-  if (nblk > 1) stage(1);
+  for (int k = 0; k < PD && k < nblk; ++k) stage(k);
   // Software pipeline over 32-pixel blocks; step k runs phase X on block k and phase W on block k-1 in
   // one instruction stream (independent work: the VALU-heavy X epilogue hides under the W MFMAs).
   //   X(k): delta_{k} B-pieces * stationary W^T -> G; epilogue: cos/sin of the phase piece this wave owns,
-  //         delta_{l-1} to HBM, sin (bf16) written back IN PLACE over the phase piece
+  //         delta_{l-1} to HBM, sin (16-bit) written back IN PLACE over the phase piece
   //   W(k-1): dW += delta^T * act, both operands read transposed (ds_read_b64_tr_b16)
   // ---- one pipeline step (block kx in phase X, block kx-1 in phase W), hand-scheduled ----------------
   // One wave per SIMD: nothing but this wave can fill the shadow of its own MFMAs, and hipcc emits MFMA
@@ -609,7 +475,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   constexpr int XS = KSX / XC;                  // k-steps per X chunk (2, or 1 for the last layer)
   constexpr int ESUB = 4;                       // epilogue slices per row tile: (q, half) groups of 4 values
   auto x_load = [&](int k, int c, u32x4* dst) {
-    const char* sD = smem + (k & (NB - 1)) * BLK;
+    const char* sD = smem + (k % NB) * BLK;
 #pragma unroll
     for (int i = 0; i < XS; ++i) dst[i] = reinterpret_cast<const u32x4*>(sD + (c * XS + i) * 1024)[lane];
   };
@@ -627,7 +493,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   u32x4 ep_p, ep_d, ep_s;
   float ep_x0 = 0.f, ep_x1 = 0.f;
   auto x_epi_sub = [&](int k, int x, int e, const f32x16& g) {
-    char* sP = smem + (k & (NB - 1)) * BLK + KSJ * 1024;
+    char* sP = smem + (k % NB) * BLK + KSJ * 1024;
     const int q = e >> 1, hf = e & 1, ks = 2 * (xit0 + x) + q;
     u32x4* pp = reinterpret_cast<u32x4*>(sP + ks * 1024) + lane;
     if (!P0 && hf == 0) ep_p = *pp;
@@ -654,11 +520,11 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
     }
   };
   auto wa_load = [&](int k, int kk, int x) -> u32x4 {   // delta^T fragment (rows = neurons of this wave's tile x)
-    const char* sD = smem + (k & (NB - 1)) * BLK;
+    const char* sD = smem + (k % NB) * BLK;
     return ds_read_tr_pair(sD, tr_addr(wr * WJ + x, kk, 0, lane), tr_addr(wr * WJ + x, kk, 1, lane));
   };
   auto wb_load = [&](int k, int kk, u32x4* dst) {       // activation fragments (cols = this wave's WI tiles)
-    const char* sP = smem + (k & (NB - 1)) * BLK + KSJ * 1024;
+    const char* sP = smem + (k % NB) * BLK + KSJ * 1024;
 #pragma unroll
     for (int y = 0; y < WI; ++y)
       dst[y] = ds_read_tr_pair(sP, tr_addr(wc * WI + y, kk, 0, lane), tr_addr(wc * WI + y, kk, 1, lane));
@@ -723,14 +589,14 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
 
   if (nblk > 0) {
     bar_all();                          // block 0 landed
-    if (2 < nblk) stage(2);
+    if (PD < nblk) stage(PD);
     asm volatile("" ::: "memory");
     step(0, true, false);
     for (int k = 1; k < nblk; ++k) {
-      // block k landed (issued two steps ago; younger: S_ST stores, one block of DMA, S_ST stores) and every
-      // wave finished step k-1
-      if (k >= 2 && k + 1 < nblk) bar_dma<2 * S_ST + G_MIN>(); else bar_all();
-      if (k + 2 < nblk) stage(k + 2);
+      // block k landed (requested PD steps ago; younger in the in-order vmcnt queue: the delta stores of the PD
+      // steps since, and the DMA of blocks k+1 .. k+PD-1) and every wave finished step k-1
+      if (k >= PD && k + PD - 1 < nblk) bar_dma<PD * S_ST + (PD - 1) * G_MIN>(); else bar_all();
+      if (k + PD < nblk) stage(k + PD);
       asm volatile("" ::: "memory");
       step(k, true, true);
     }
@@ -753,6 +619,92 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
       if (hh == 0) slab[JW * IW + 32 * (wr * WJ + x) + cl] = tsum;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dw0: weight gradient of layer 0 (no data gradient below it): dW_0[j][c] = sum_pixels delta_0[pix][j] * x_c[pix].
+//   delta_0 blocks stream through a 4-slot LDS ring (LDS-DMA two blocks ahead, as in k_bwd) and are read
+//   transposed; the B operand is built in registers from the pixel coordinates, split in two 16-bit terms
+//   (columns x0_hi, x0_lo, x1_hi, x1_lo: hi + lo keeps 2x the significand of one 16-bit value), so the
+//   kernel touches HBM for delta_0 only.  One 32-row tile of the slab per wave.
+// ---------------------------------------------------------------------------------------------
+struct Dw0Args {
+  const u32x4* D;       // delta image of layer 0 (JW/16 k-steps per pixel block)
+  long n_pb;
+  float* slab;          // [gridDim.x][JW*32 + JW]
+  long pix0, npix;
+  int W, row_begin;
+  unsigned long long w_magic;
+  float inv_hm1, inv_wm1;   // 1/(H-1), 1/(W-1): torch.linspace(0,1,n)[i] = i/(n-1) to within 1 ulp (enough for a
+                            // gradient term; the forward uses the exact vectors).  No loads in the DMA loop.
+};
+
+template <int JW, typename OP>
+__global__ __launch_bounds__(JW * 2) void k_dw0(Dw0Args a) {
+  constexpr int NW = JW / 32, KSJ = JW / 16, NB = 8, PD = NB - 2, BLK = KSJ * 1024;   // 96 KiB in flight at JW = 256
+  constexpr int G_MIN = KSJ / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long pb_begin = blockIdx.x, pb_step = gridDim.x;
+  const int nblk = (int)((a.n_pb - pb_begin + pb_step - 1) / pb_step);
+  f32x16 acc = {};
+  float dbs = 0.f;
+  auto stage = [&](int k) {
+    char* base = smem + (k % NB) * BLK;
+    const long pb = pb_begin + k * pb_step;
+    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * KSJ + pc) * 64 + lane, base + pc * 1024);
+  };
+  // B operand = coordinates of the block's 32 pixels as 16-bit columns {x0_hi, x0_lo, x1_hi, x1_lo}.  Wave 0
+  // builds a [4][32] table per block (one pixel per lane, one integer division), double-buffered by block
+  // parity behind the ring; every wave then reads its fragment with one ds_read_b128 per k-step.
+  uint16_t* sXY = reinterpret_cast<uint16_t*>(smem + NB * BLK);          // [2][4][32]
+  auto build_xy = [&](int k) {
+    if (wave == 0 && lane < 32) {
+      long p = a.pix0 + (pb_begin + (long)k * pb_step) * 32 + lane;
+      if (p >= a.npix) p = a.npix - 1;
+      const unsigned row = (unsigned)(((unsigned long long)p * a.w_magic) >> 40);
+      const unsigned col = (unsigned)(p - (long)row * a.W);
+      const float x0 = ((float)(row + (unsigned)a.row_begin) * a.inv_hm1 - 0.5f) * 2.0f;
+      const float x1 = ((float)col * a.inv_wm1 - 0.5f) * 2.0f;
+      const uint32_t h0 = OP::pack2(x0, 0.f), h1 = OP::pack2(x1, 0.f);
+      uint16_t* t = sXY + (k & 1) * 128 + lane;
+      t[0] = (uint16_t)h0;
+      t[32] = (uint16_t)OP::pack2(x0 - OP::lo(h0), 0.f);
+      t[64] = (uint16_t)h1;
+      t[96] = (uint16_t)OP::pack2(x1 - OP::lo(h1), 0.f);
+    }
+  };
+  auto coord_frag = [&](int k, int kk) -> u32x4 {   // lane (col c = lane&31, hq = lane>>5): pixels 16*kk + 8*hq + j
+    const int c = lane & 31;
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (c < 4) o = *reinterpret_cast<const u32x4*>(sXY + (k & 1) * 128 + c * 32 + 16 * kk + 8 * (lane >> 5));
+    return o;
+  };
+  for (int k = 0; k < PD && k < nblk; ++k) stage(k);
+  build_xy(0);
+  for (int k = 0; k < nblk; ++k) {
+    if (k >= PD && k + PD - 1 < nblk) bar_dma<(PD - 1) * G_MIN>(); else bar_all();
+    if (k + PD < nblk) stage(k + PD);
+    asm volatile("" ::: "memory");
+    if (k + 1 < nblk) build_xy(k + 1);
+    const u32x4 fb0 = coord_frag(k, 0), fb1 = coord_frag(k, 1);
+    const char* sD = smem + (k & (NB - 1)) * BLK;
+    const u32x4 fa0 = ds_read_tr_pair(sD, tr_addr(wave, 0, 0, lane), tr_addr(wave, 0, 1, lane));
+    const u32x4 fa1 = ds_read_tr_pair(sD, tr_addr(wave, 1, 0, lane), tr_addr(wave, 1, 1, lane));
+    acc = OP::mfma(fa0, fb0, acc);
+    acc = OP::mfma(fa1, fb1, acc);
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t += OP::sum2(fa0[e]) + OP::sum2(fa1[e]);
+    dbs += t;
+  }
+  float* slab = a.slab + (size_t)blockIdx.x * (JW * 32 + JW);
+  const int cl = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) slab[(size_t)(32 * wave + rho(t, hh)) * 32 + cl] = acc[t];
+  const float tsum = dbs + __shfl_xor(dbs, 32);
+  if (hh == 0) slab[JW * 32 + 32 * wave + cl] = tsum;
 }
 
 // ---------------------------------------------------------------------------------------------
