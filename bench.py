@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the multi-process "
+                         "path with several ranks on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--mode", default="per-image", choices=["per-image", "pixel-split"],
                     help="N>1: per-image = one independent fit per GPU (weak scaling, no collective); "
                          "pixel-split = ONE image, rows sharded over ranks, gradient all-reduce over RCCL (strong scaling)")
@@ -97,8 +101,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from implicit_image._engine import SirenEngine
     dev = torch.device("cuda", local_rank)
@@ -144,14 +153,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     rep = eng.profile_report()
     eng.profile(False)
     _, sse = eng.forward(want_pred=False)
     if split:
-        t = torch.tensor([sse], device=dev, dtype=torch.float64)
+        t = torch.tensor([sse], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t)
         sse = t.item()
     psnr = 10 * torch.log10(torch.tensor(3.0 * H * W / sse)).item()
@@ -177,7 +186,7 @@ def main():
             "metric": "Mpixel-iters/s (fwd+bwd+Adam) @ SIREN-256x8",
             "value": value, "unit": "Mpixel-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if split else "weak",
-            "vs_baseline": None, "dtype": "f16 fwd / bf16 bwd operands, f32 accumulate" if args.dtype == "f16" else "bf16",
+            "vs_baseline": None, "dtype": "f16 (fp16 MFMA operands fwd+bwd, f32 accumulate, f32 optimiser state)" if args.dtype == "f16" else "bf16",
             "data": "synthetic",
             "config": {"workload": f"siren_{args.hidden}x{args.depth}_fit_step_{H}x{W}x3_grid", "image": f"{H}x{W}x3",
                        "hidden": args.hidden, "depth": args.depth, "sharding": (f"pixel-split rows x{world} + RCCL grad all-reduce" if split else f"per-image x{world}"),

@@ -46,7 +46,12 @@ class PixelSplitFit:
                                     device=g.device)
         self._buf[:-1].copy_(g)
         self._buf[-1] = sse
-        self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.dist.get_backend(self.group) == "gloo" and self._buf.is_cuda:   # rehearsal path: gloo reduces on the host
+            host = self._buf.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._buf.copy_(host)
+        else:
+            self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM, group=self.group)
         self.backend.set_grads(self._buf[:-1].to(g.dtype).contiguous())
         self.backend.adam_step(lr)
         return float(self._buf[-1].item()) / self.n_values
