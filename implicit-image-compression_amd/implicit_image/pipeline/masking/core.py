@@ -6,8 +6,10 @@ Differences from the reference are deliberate and documented:
   * the FLOP counter (pipeline/masking/counting/) is logging only and is not rebuilt, but the two
     `torch.rand(*input_size)` draws it makes on the CPU generator (core.py:371,384) ARE reproduced,
     because the ERK masks drawn between them depend on the generator position.
-Supported registry keys: sparse_init erdos-renyi(-kernel); prune_mode magnitude; growth_mode
-absolute-gradient | none; redistribution_mode none | nonzero; decay cosine.
+Supported registry keys: sparse_init erdos-renyi(-kernel) | random | resume; prune_mode magnitude |
+global-magnitude; growth_mode absolute-gradient | momentum | random | none; redistribution_mode none |
+nonzero | momentum | grad; decay cosine | linear | magnitude-prune.  (The struct-* modes act on 4-D conv
+kernels and have no meaning for a SIREN; lottery-ticket init loads a pickle and is not provided.)
 """
 import logging
 from dataclasses import dataclass, field
@@ -61,11 +63,47 @@ class Masking:
         self.name2prune_rate = {}
         self.stats = LayerStats()
         self._pushed_engine = None
+        # global growth/prune state (core.py:151-156)
+        self.prune_threshold, self.growth_threshold = 0.001, 0.001
+        self.growth_increment, self.increment, self.tolerance = 0.2, 0.2, 1e-6
 
     # ---- properties -------------------------------------------------------------------------
     @property
     def prune_rate(self) -> float:
         return self.prune_rate_decay.get_dr()
+
+    @property
+    def global_prune(self) -> bool:
+        return "global" in self.prune_mode
+
+    def get_momentum_for_weight(self, weight) -> torch.Tensor:
+        """Adam: m / (sqrt(v) + 1e-8); SGD: momentum buffer (core.py:474-493)."""
+        st = self.optimizer.state[weight]
+        if "exp_avg" in st:
+            return st["exp_avg"] / (torch.sqrt(st["exp_avg_sq"]) + 1e-08)
+        return st["momentum_buffer"]
+
+    def calc_redistributed_densities(self):
+        """Per-layer regrowth counts proportional to the redistribution statistic, capped at 99 % of the free
+        slots with the overflow spread over the other layers (core.py:299-360)."""
+        residual, mean_residual, name2regrowth, i = 9999, 0, {}, 0
+        while residual > 0 and i < 1000:
+            residual = 0
+            for name in self.stats.variance_dict:
+                max_regrowth = self.stats.zeros_dict[name] + self.stats.removed_dict[name]
+                if name in name2regrowth:
+                    regrowth = name2regrowth[name]
+                else:
+                    regrowth = round(self.stats.variance_dict[name] * (self.stats.total_removed + self.adjusted_growth))
+                regrowth += mean_residual
+                if regrowth > 0.99 * max_regrowth:
+                    name2regrowth[name] = 0.99 * max_regrowth
+                    residual += regrowth - name2regrowth[name]
+                else:
+                    name2regrowth[name] = regrowth
+            mean_residual = residual / len(name2regrowth) if name2regrowth else 0
+            i += 1
+        return name2regrowth
 
     # ---- setup (core.py:220-248, 386-423) ---------------------------------------------------
     def add_module(self, module: nn.Module):
@@ -138,7 +176,10 @@ class Masking:
             self.apply_mask()                   # otherwise fused into the engine's Adam kernel
         if not self.dense_gradients:
             self.reset_momentum()
-        self.prune_rate_decay.step(self.mask_step)
+        if self.prune_rate_decay.mode == "cumulative":
+            self.prune_rate_decay.step(self.mask_step, 1 - self.stats.total_density)
+        else:
+            self.prune_rate_decay.step(self.mask_step)
         self.mask_step += 1
 
     # ---- topology update (core.py:425-464, 250-269, 713-801) ----------------------------------
@@ -177,23 +218,30 @@ class Masking:
         self.gather_statistics()
         self.adjust_prune_rate()
         prune = prune_registry[self.prune_mode]
-        for name, weight in self.module.named_parameters():
-            if name not in self.mask_dict:
-                continue
-            new_mask = prune(self, self.mask_dict[name], weight, name)
-            removed = self.stats.nonzeros_dict[name] - int(new_mask.sum().item())
-            self.stats.total_removed += removed
-            self.stats.removed_dict[name] = removed
-            self.mask_dict[name] = new_mask
+        if self.global_prune:
+            self.stats.total_removed = prune(self)
+        else:
+            for name, weight in self.module.named_parameters():
+                if name not in self.mask_dict:
+                    continue
+                new_mask = prune(self, self.mask_dict[name], weight, name)
+                removed = self.stats.nonzeros_dict[name] - int(new_mask.sum().item())
+                self.stats.total_removed += removed
+                self.stats.removed_dict[name] = removed
+                self.mask_dict[name] = new_mask
         total_nonzero_new = 0
         if self.growth_mode == "none":
             total_nonzero_new = self.stats.total_nonzero - self.stats.total_removed
         else:
             grow = grow_registry[self.growth_mode]
+            redistribute = self.redistribution_mode not in ["nonzero", "none"]
+            if redistribute:
+                name2regrowth = self.calc_redistributed_densities()
             for name, weight in self.module.named_parameters():
                 if name not in self.mask_dict:
                     continue
-                new_mask = grow(self, name, self.stats.removed_dict[name], weight)
+                num_growth = name2regrowth[name] if redistribute else self.stats.removed_dict[name]
+                new_mask = grow(self, name, num_growth, weight)
                 total_nonzero_new += new_mask.sum().item()
                 self.mask_dict.pop(name)
                 self.mask_dict[name] = new_mask.float()

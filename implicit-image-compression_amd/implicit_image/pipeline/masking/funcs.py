@@ -54,9 +54,35 @@ def erk_init(masking, is_kernel: bool = True, **_):
     masking.erk_probs = probs
 
 
+def random_init(masking, **_):
+    """init_scheme.py:181-206: every layer keeps `density` of its weights at random; the FIRST parameter is
+    taken out of the mask set altogether (stays dense)."""
+    for e, (name, weight) in enumerate(masking.module.named_parameters()):
+        if e == 0:
+            masking.mask_dict.pop(name, None)
+            continue
+        if name not in masking.mask_dict:
+            continue
+        masking.mask_dict[name] = (torch.rand(weight.shape) < masking.density).float()
+        masking.baseline_nonzero += int(masking.mask_dict[name].sum().int().item())
+        masking.total_params += weight.numel()
+
+
+def resume_init(masking, **_):
+    """init_scheme.py:209-228: mask = currently non-zero weights."""
+    for name, weight in masking.module.named_parameters():
+        if name not in masking.mask_dict:
+            continue
+        masking.mask_dict[name] = (weight != 0.0).float().cpu()
+        masking.baseline_nonzero += int(masking.mask_dict[name].sum().int().item())
+        masking.total_params += weight.numel()
+
+
 init_registry = {
     "erdos-renyi-kernel": erk_init,
     "erdos-renyi": lambda m, **kw: erk_init(m, is_kernel=False, **kw),
+    "random": random_init,
+    "resume": resume_init,
 }
 
 
@@ -73,7 +99,43 @@ def magnitude_prune(masking, mask: torch.Tensor, weight: torch.Tensor, name: str
     return mask
 
 
-prune_registry = {"magnitude": magnitude_prune}
+def global_magnitude_prune(masking) -> int:
+    """prune.py:54-104: one global |w| threshold, adapted multiplicatively until the number of removed
+    weights is within `tolerance` of ceil(prune_rate * baseline_nonzero) (or 10 stalled tries); masks are
+    then rewritten in place as |w| > threshold."""
+    tokill = math.ceil(masking.prune_rate * masking.baseline_nonzero)
+    if tokill <= 0:
+        return 0
+    total_removed, prev_removed = 0, 0
+    increment, tries = masking.increment, 0
+    while abs(total_removed - tokill) > tokill * masking.tolerance:
+        total_removed = 0
+        for name, weight in masking.module.named_parameters():
+            if name not in masking.mask_dict:
+                continue
+            remain = (torch.abs(weight.data) > masking.prune_threshold).sum().item()
+            total_removed += masking.stats.nonzeros_dict[name] - remain
+        if prev_removed == total_removed:
+            tries += 1
+            if tries == 10:
+                break
+        else:
+            tries = 0
+        prev_removed = total_removed
+        if total_removed > tokill * (1.0 + masking.tolerance):
+            masking.prune_threshold *= 1.0 - increment
+            increment *= 0.99
+        elif total_removed < tokill * (1.0 - masking.tolerance):
+            masking.prune_threshold *= 1.0 + increment
+            increment *= 0.99
+    for name, weight in masking.module.named_parameters():
+        if name not in masking.mask_dict:
+            continue
+        masking.mask_dict[name][:] = (torch.abs(weight.data) > masking.prune_threshold)
+    return int(total_removed)
+
+
+prune_registry = {"magnitude": magnitude_prune, "global-magnitude": global_magnitude_prune}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -91,7 +153,39 @@ def abs_grad_growth(masking, name: str, total_regrowth: int, weight: torch.Tenso
     return new_mask
 
 
-grow_registry = {"absolute-gradient": abs_grad_growth}
+def momentum_growth(masking, name: str, total_regrowth: int, weight: torch.Tensor) -> torch.Tensor:
+    """grow.py:25-55: grow where |Adam momentum| = |m / (sqrt(v) + 1e-8)| is largest among masked-out entries
+    (the weights themselves are NOT reset by this mode)."""
+    new_mask = masking.mask_dict[name].data.bool()
+    momentum = masking.get_momentum_for_weight(weight)
+    momentum = momentum * (new_mask == 0).to(momentum.dtype)
+    _, idx = torch.sort(torch.abs(momentum).flatten(), descending=True)
+    new_mask.data.view(-1)[idx[: int(total_regrowth)]] = True
+    return new_mask
+
+
+def random_growth(masking, name: str, total_regrowth: int, weight: torch.Tensor) -> torch.Tensor:
+    """grow.py:100-136: Bernoulli(total_regrowth / #zeros) growth among masked-out entries (device RNG of the
+    mask tensor); grown and still-masked weights are zeroed."""
+    new_mask = masking.mask_dict[name].data.bool()
+    n = (new_mask == 0).sum().item()
+    if n == 0:
+        return new_mask
+    prob = total_regrowth / n
+    new_weights = torch.zeros_like(new_mask).bool()
+    new_weights[new_mask == 0] = torch.rand_like(new_weights[new_mask == 0].float()) < prob
+    new_mask = new_mask.bool() | new_weights.bool()
+    weight.data[new_weights == 1] = 0.0
+    weight.data[new_mask == 0] = 0.0
+    return new_mask
+
+
+def no_growth(masking, name: str, total_regrowth: int, weight: torch.Tensor) -> torch.Tensor:
+    return masking.mask_dict[name].data.bool()
+
+
+grow_registry = {"absolute-gradient": abs_grad_growth, "momentum": momentum_growth, "random": random_growth,
+                 "none": no_growth}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -101,7 +195,17 @@ def nonzero_statistic(masking, name, weight, mask) -> float:
     return (weight != 0.0).sum().item()
 
 
-redistribute_registry = {"none": nonzero_statistic, "nonzero": nonzero_statistic}
+def momentum_statistic(masking, name, weight, mask) -> float:
+    """redistribute.py:18-37: mean |Adam momentum| over the active weights."""
+    return torch.abs(masking.get_momentum_for_weight(weight)[mask.bool()]).mean().item()
+
+
+def grad_statistic(masking, name, weight, mask) -> float:
+    return torch.abs(weight.grad[mask.bool()]).mean().item()
+
+
+redistribute_registry = {"none": nonzero_statistic, "nonzero": nonzero_statistic, "momentum": momentum_statistic,
+                         "grad": grad_statistic}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -136,4 +240,60 @@ class CosineDecay:
         return self._rate
 
 
-decay_registry = {"cosine": CosineDecay}
+class LinearDecay:
+    """decay.py:73-112."""
+    mode = "current"
+
+    def __init__(self, prune_rate: float = 0.3, T_max: int = 1000):
+        self._step, self.T_max = 0, T_max
+        self.decrement = prune_rate / float(T_max)
+        self.current_prune_rate = self.initial_prune_rate = prune_rate
+
+    def step(self, step: int = -1, *_):
+        if step >= 0:
+            if self._step < self.T_max:
+                self.current_prune_rate = self.initial_prune_rate - self.decrement * (step + 1)
+                self._step = step + 1
+            else:
+                self._step = self.T_max
+            return
+        if self._step < self.T_max:
+            self.current_prune_rate -= self.decrement
+            self._step += 1
+
+    def get_dr(self) -> float:
+        return self.current_prune_rate
+
+
+class MagnitudePruneDecay:
+    """decay.py:115-158 (Zhu & Gupta cubic cumulative-sparsity schedule; prune rate = finite difference
+    against the CURRENT sparsity handed in by Masking.step)."""
+    mode = "cumulative"
+
+    def __init__(self, initial_sparsity: float = 0.0, final_sparsity: float = 0.3, T_max: int = 30000,
+                 T_start: int = 350, interval: int = 100):
+        self.initial_sparsity, self.final_sparsity = initial_sparsity, final_sparsity
+        self.T_max, self.T_start, self.interval = T_max, T_start, interval
+        self.current_prune_rate, self._step = 0.0, 0
+
+    def cumulative_sparsity(self, step):
+        if step < self.T_start:
+            return self.initial_sparsity
+        if step < self.T_max:
+            mul = (1 - (step - self.T_start) / (self.T_max - self.T_start)) ** 3
+            return self.final_sparsity + (self.initial_sparsity - self.final_sparsity) * mul
+        return self.final_sparsity
+
+    def step(self, step: int = -1, current_sparsity=-1):
+        if step == -1:
+            step = self._step
+        if current_sparsity == -1:
+            current_sparsity = self.cumulative_sparsity(step - self.interval)
+        self.current_prune_rate = max(self.cumulative_sparsity(step) - current_sparsity, 0)
+        self._step = step + 1
+
+    def get_dr(self) -> float:
+        return self.current_prune_rate
+
+
+decay_registry = {"cosine": CosineDecay, "linear": LinearDecay, "magnitude-prune": MagnitudePruneDecay}

@@ -96,8 +96,14 @@ def setup_mask(model: Module, optim: Optimizer, masking_cfg=None) -> Masking:
     schedule = _cfg_get(masking_cfg, "decay_schedule")
     if schedule not in decay_registry:
         raise NotImplementedError(f"decay_schedule '{schedule}' is outside the accelerated RigL path")
-    decay = decay_registry[schedule](prune_rate=_cfg_get(masking_cfg, "prune_rate"),
-                                     T_max=_cfg_get(masking_cfg, "end_when"))
+    if schedule == "magnitude-prune":                                              # reference :100-106
+        decay = decay_registry[schedule](final_sparsity=1 - _cfg_get(masking_cfg, "final_density"),
+                                         T_max=_cfg_get(masking_cfg, "end_when"),
+                                         T_start=_cfg_get(masking_cfg, "start_when"),
+                                         interval=_cfg_get(masking_cfg, "interval"))
+    else:
+        decay = decay_registry[schedule](prune_rate=_cfg_get(masking_cfg, "prune_rate"),
+                                         T_max=_cfg_get(masking_cfg, "end_when"))
     mask = Masking(optim, decay, input_size=(1, 1, 2), density=_cfg_get(masking_cfg, "density"),
                    dense_gradients=_cfg_get(masking_cfg, "dense_gradients"),
                    sparse_init=_cfg_get(masking_cfg, "sparse_init"), prune_mode=_cfg_get(masking_cfg, "prune_mode"),
