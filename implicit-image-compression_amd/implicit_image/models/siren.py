@@ -62,6 +62,14 @@ class Siren(nn.Module):
         # fills with per-Linear forward-pre and backward hooks (k-means quantisation, pipeline/quant/kmeans.py:39-55)
         self.pre_pass_callbacks = []
         self.post_backward_callbacks = []
+        # hidden widths the kernels are instantiated for; any other width <= 256 (e.g. Small_Dense's
+        # int(hidden * sqrt(density)), reference siren.py:88) runs zero-padded to the next one: padded neurons
+        # have zero weights and bias, output sin(0) = 0 and receive exactly zero gradients, so they stay zero
+        self._engine_width = next((w for w in (32, 64, 128, 256) if w >= hidden_size), None)
+        if self._engine_width is None:
+            raise NotImplementedError(f"hidden_size {hidden_size} > 256 is not supported by the gfx950 engine yet")
+        self._padded = self._engine_width != hidden_size
+        self._pad_index = None
         self._engine = None
         self._engine_key = None
         self._grid_key = None
@@ -89,7 +97,7 @@ class Siren(nn.Module):
             c = self.cfg
             if self._engine is not None:
                 self._unbind()
-            self._engine = SirenEngine(H, w, c["hidden_size"], c["depth"], c["first_omega_0"], c["hidden_omega_0"],
+            self._engine = SirenEngine(H, w, self._engine_width, c["depth"], c["first_omega_0"], c["hidden_omega_0"],
                                        c["outermost_linear"], c["output_size"], c["compute_dtype"],
                                        device=grid.device.index or 0, row_begin=row_begin, row_end=row_end,
                                        chunk_pixels=c["chunk_pixels"])
@@ -112,10 +120,34 @@ class Siren(nn.Module):
         self._sync_to_engine()
         return eng
 
+    def _padded_index(self, device):
+        """flat index of every logical parameter element inside the engine's (wider) flat layout"""
+        if self._pad_index is None or self._pad_index.device != device:
+            c, wp = self.cfg, self._engine_width
+            idx, off = [], 0
+            for l in range(c["depth"]):
+                fin = c["input_size"] if l == 0 else c["hidden_size"]
+                fout = c["output_size"] if l == c["depth"] - 1 else c["hidden_size"]
+                fin_p = c["input_size"] if l == 0 else wp
+                fout_p = c["output_size"] if l == c["depth"] - 1 else wp
+                r = torch.arange(fout, device=device)[:, None] * fin_p + torch.arange(fin, device=device)[None, :]
+                idx.append((off + r).reshape(-1))
+                off += fin_p * fout_p
+                idx.append(off + torch.arange(fout, device=device))
+                off += fout_p
+            self._pad_index = torch.cat(idx)
+        return self._pad_index
+
     def _sync_to_engine(self):
         """(Re)bind every Parameter to its slice of the engine's flat buffers.  Code that REPLACED
-        `weight.data` (e.g. `weight.data = weight.data * mask`) is detected by pointer and copied in."""
+        `weight.data` (e.g. `weight.data = weight.data * mask`) is detected by pointer and copied in.
+        Padded widths: parameters stay ordinary tensors and are scattered into the engine every pass."""
         eng = self._engine
+        if self._padded:
+            flat = torch.zeros(eng.num_params, device=eng.device)
+            flat[self._padded_index(eng.device)] = torch.cat([p.data.reshape(-1).float() for p in self._param_list()])
+            eng.set_params(flat)
+            return
         flat, grads = eng.view("params"), eng.view("grads")
         off = 0
         for p in self._param_list():
@@ -130,10 +162,40 @@ class Siren(nn.Module):
             off += n
         eng.params_changed()   # in-place edits through the views are invisible to the engine: always refresh
 
+    def _gather_from_engine(self, which: str):
+        """padded widths only: logical slices of an engine state vector ('params' | 'grads' | 'exp_avg' | ...)"""
+        flat = self._engine.view(which)[self._padded_index(self._engine.device)]
+        out, off = [], 0
+        for p in self._param_list():
+            out.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return out
+
+    def download_grads(self):
+        if self._padded:
+            for p, g in zip(self._param_list(), self._gather_from_engine("grads")):
+                p.grad = g.clone()
+
+    def download_params(self):
+        if self._padded:
+            with torch.no_grad():
+                for p, v in zip(self._param_list(), self._gather_from_engine("params")):
+                    p.data.copy_(v)
+
+    def set_engine_masks(self, flat_logical: torch.Tensor):
+        """0/1 mask per logical parameter element -> engine (scattered into the wider layout when padded)."""
+        eng = self._engine
+        if self._padded:
+            full = torch.zeros(eng.num_params, device=eng.device)
+            full[self._padded_index(eng.device)] = flat_logical.to(eng.device).float()
+            eng.set_masks(full)
+        else:
+            eng.set_masks(flat_logical.contiguous())
+
     def _unbind(self):
         for p in self._param_list():
             p.data = p.data.clone()
-            p.grad = None
+            p.grad = None if not self._padded else p.grad
         self._engine.close()
         self._engine = None
 

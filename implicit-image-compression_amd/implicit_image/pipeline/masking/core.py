@@ -138,7 +138,7 @@ class Masking:
         for name, weight in self.module.named_parameters():
             mk = self.mask_dict.get(name)
             parts.append((mk if mk is not None else torch.ones_like(weight)).reshape(-1).float())
-        eng.set_masks(torch.cat(parts).contiguous())
+        self.module.set_engine_masks(torch.cat(parts))
         self._pushed_engine = eng
 
     # ---- per-step (core.py:271-289, 671-702) ------------------------------------------------

@@ -39,6 +39,13 @@ class EngineAdam(Optimizer):
         self._bound = None
 
     def _bind_state(self, eng):
+        if getattr(self.model, "_padded", False):     # padded widths: logical copies, refreshed after every step
+            for p, m, v in zip(self.model._param_list(), self.model._gather_from_engine("exp_avg"),
+                               self.model._gather_from_engine("exp_avg_sq")):
+                st = self.state[p]
+                st.setdefault("step", torch.tensor(0.0))
+                st["exp_avg"], st["exp_avg_sq"] = m.clone(), v.clone()
+            return
         if self._bound is eng:
             return
         m, v = eng.view("exp_avg"), eng.view("exp_avg_sq")
@@ -60,8 +67,12 @@ class EngineAdam(Optimizer):
         eng = getattr(self.model, "_engine", None)
         if eng is None:
             raise RuntimeError("EngineAdam.step() before any forward/backward: the engine is created by train_epoch")
-        self._bind_state(eng)
+        if not getattr(self.model, "_padded", False):
+            self._bind_state(eng)
         eng.adam_step(float(self.param_groups[0]["lr"]))
+        if getattr(self.model, "_padded", False):
+            self.model.download_params()
+            self._bind_state(eng)
         for p in self.model._param_list():
             self.state[p]["step"] += 1
         return None
@@ -131,6 +142,7 @@ def train_epoch(model: Module, optim: Optimizer, grid, img, **kwargs) -> float:
     eng = model.engine(grid, img)
     sse = eng.forward_backward(sync=True)
     loss = sse / (img.shape[0] * img.shape[1] * img.shape[2])
+    model.download_grads()             # no-op unless the width is zero-padded
     for cb in list(getattr(model, "post_backward_callbacks", ())):
         cb()
     if mask:

@@ -350,3 +350,29 @@ def test_make_fit_quant_and_compress_tail(tmp_path, monkeypatch):
     assert res["Compressed Bytes"] == os.path.getsize(meta_dir / "compressed_weights.data")
     # 2 quantised 64x64 layers: 4096 one-byte labels each instead of 8192 bytes of fp16
     assert res["Compressed Bytes"] < 2 * (64 * 64 * 1 + 256 * 2) + (64 * 2 + 64 + 3 * 64 + 3 + 128) * 2 + 64
+
+
+def test_small_dense_width_runs_zero_padded():
+    """masking=Small_Dense narrows the net to int(hidden*sqrt(density)) (reference siren.py:88): 57 for 128 @ 0.2.
+    The engine runs it zero-padded to 64; losses must track the fp32 oracle at the LOGICAL width."""
+    from implicit_image.data import get_grid
+    from implicit_image.models import registry
+    from implicit_image.utils.train_helper import eval_epoch, get_optimizer_lr_scheduler, train_epoch
+    H = W = 48
+    torch.manual_seed(0)
+    model = registry["siren"](depth=4, hidden_size=128, first_omega_0=50, hidden_omega_0=30,
+                              small_dense_density=0.2).to("cuda")
+    assert model.cfg["hidden_size"] == 57 and model._engine_width == 64
+    p = [q.detach().cpu().clone() for q in model._param_list()]
+    img, grid = so.synthetic_image(H, W, seed=3), get_grid(H, W)
+    optim, sched = get_optimizer_lr_scheduler(model, dict(name="adam", lr=3e-4))
+    opt = so.Adam(p)
+    got = [train_epoch(model, optim, grid.cuda(), img.cuda(), lr_scheduler=sched) for _ in range(30)]
+    ref = [so.train_epoch(p, opt, so.get_grid(H, W), img, t) for t in range(30)]
+    assert np.max(np.abs(np.array(got) - np.array(ref)) / np.array(ref)) <= 2e-3
+    w1 = dict(model.named_parameters())["layers.1.linear.weight"]
+    assert tuple(w1.shape) == (57, 57) and w1.grad is not None and tuple(w1.grad.shape) == (57, 57)
+    assert (w1.detach().cpu() - p[2]).abs().max().item() <= 2e-3      # 30 Adam steps of 3e-4 each; sign flips on ~0 gradients
+    _, _, psnr, _ = eval_epoch(model, grid.cuda(), img.cuda())
+    _, _, psnr_ref, _ = so.eval_epoch(p, so.get_grid(H, W), img)
+    assert abs(psnr - psnr_ref) <= 0.05
