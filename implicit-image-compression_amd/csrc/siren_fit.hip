@@ -6,6 +6,7 @@
 // The sequence mirrors one `train_epoch` of the reference (implicit_image/utils/train_helper.py:132-185)
 // for the full-batch grid (implicit_image/compress.py:137-138).
 #include "siren_kernels.hip"
+#include "siren_wide.hip"
 
 #include <math.h>
 #include <stdio.h>
@@ -54,6 +55,8 @@ struct sf_engine {
   // images
   uint16_t *wf = nullptr, *wf_last = nullptr, *wb = nullptr, *wb_last = nullptr;
   f32x4* l0tab = nullptr;
+  float* biasw = nullptr;   // wide path: pre-scaled fp32 biases of layers 1..D-1
+  bool wide = false;        // hidden > 256: layer-at-a-time kernels (siren_wide.hip)
   bool images_dirty = true;
   float wscale = 1.f;
   float gpre = 1.f;       // power-of-two pre-scale of dL/dout (fp16 backward operands), undone in k_reduce*
@@ -217,8 +220,10 @@ int launch_fwd(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
+int refresh_images_wide(sf_engine* h);
 int refresh_images(sf_engine* h) {
   if (!h->images_dirty) return SF_OK;
+  if (h->wide) return refresh_images_wide(h);
   ImgArgs a;
   memset(&a, 0, sizeof(a));
   a.params = h->params;
@@ -256,9 +261,215 @@ double flops_bwdx_px_unused(const sf_engine* h) {
   return 2.0 * ((h->D - 2) * W * W + h->cfg.out_features * W);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// wide path (hidden 512 / 1024): layer-at-a-time kernels of siren_wide.hip
+// ---------------------------------------------------------------------------------------------------------
+int refresh_images_wide(sf_engine* h) {
+  if (!h->images_dirty) return SF_OK;
+  const int WD = h->WD, D = h->D, NBLK = WD / 256, KS = WD / 16;
+  const bool f16 = h->cfg.compute_dtype == SF_F16;
+  Launch L(h, K_IMAGES, 0, (double)(D - 2) * WD * WD * 8.0);
+  {
+    WTabArgs t;
+    memset(&t, 0, sizeof(t));
+    t.params = h->params; t.depth = D; t.WD = WD; t.out_features = h->cfg.out_features;
+    t.off_w0 = h->off_w[0]; t.off_b0 = h->off_b[0];
+    for (int l = 0; l < D; ++l) t.off_b[l] = h->off_b[l];
+    t.wscale = h->wscale; t.l0tab = h->l0tab; t.bias = h->biasw;
+    long n = (long)(D - 2) * WD;
+    if (n < WD) n = WD;
+    hipLaunchKernelGGL(k_wtables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, t);
+  }
+  auto image = [&](int l, bool transpose, int OT, int n_ob, int n_chunk, float scale, uint16_t* dst) {
+    WImgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W = h->params + h->off_w[l];
+    a.rows = l == D - 1 ? h->cfg.out_features : WD; a.cols = WD;
+    a.transpose = transpose; a.OT = OT; a.n_ob = n_ob; a.n_chunk = n_chunk; a.scale = scale; a.f16 = f16; a.dst = dst;
+    const long total = (long)n_ob * n_chunk * OT * 4 * 512;
+    hipLaunchKernelGGL(k_wimage, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
+  };
+  for (int l = 1; l <= D - 2; ++l) {
+    image(l, false, 8, NBLK, KS / 4, h->wscale, h->wf + (size_t)(l - 1) * WD * WD);
+    image(l, true, 8, NBLK, KS / 4, l - 1 == 0 ? h->cfg.first_omega_0 : h->cfg.hidden_omega_0, h->wb + (size_t)(l - 1) * WD * WD);
+  }
+  image(D - 1, false, 1, 1, KS / 4, h->wscale, h->wf_last);
+  image(D - 1, true, 8, NBLK, 1, D - 2 == 0 ? h->cfg.first_omega_0 : h->cfg.hidden_omega_0, h->wb_last);
+  L.done();
+  HIPCHK(hipGetLastError());
+  h->images_dirty = false;
+  return SF_OK;
+}
+
+template <int MODE>
+int launch_wgemm(sf_engine* h, const WGemmArgs& a, int n_super, int n_ob) {
+  const size_t lds = (size_t)4 * (MODE == 1 ? 1 : 8) * 4 * 1024 + 64;
+  const bool f16 = h->cfg.compute_dtype == SF_F16;
+  int rc = f16 ? set_lds(k_wgemm<MODE, OpF16>, lds) : set_lds(k_wgemm<MODE, OpBF16>, lds);
+  if (rc) return rc;
+  if (f16) hipLaunchKernelGGL((k_wgemm<MODE, OpF16>), dim3(n_super, n_ob), dim3(512), lds, h->stream, a);
+  else hipLaunchKernelGGL((k_wgemm<MODE, OpBF16>), dim3(n_super, n_ob), dim3(512), lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
+  int rc = refresh_images_wide(h);
+  if (rc) return rc;
+  const int WD = h->WD, D = h->D, KS = WD / 16, NBLK = WD / 256;
+  const bool f16 = h->cfg.compute_dtype == SF_F16;
+  const double two_pi = 6.283185307179586476925286766559;
+  const float sc_first = (float)((double)h->cfg.first_omega_0 / two_pi);
+  const float sc_hidden = (float)((double)h->cfg.hidden_omega_0 / two_pi / (double)h->wscale);
+  const long n_chunks = (h->npix + h->chunk_px - 1) / h->chunk_px;
+  const size_t blk_pieces = (size_t)(KS / 4) * 32;   // pieces of one [256 x WD] block of a hidden image
+  long sse_off = 0;
+  for (long c = 0; c < n_chunks; ++c) {
+    const long pix0 = c * h->chunk_px;
+    long px = h->npix - pix0;
+    if (px > h->chunk_px) px = h->chunk_px;
+    const int n_super = (int)((px + kSuper - 1) / kSuper);
+    const long n_pb = (long)n_super * kWavesFwd;
+    const double npx = n_pb * 32.0;
+    // ---- forward ----
+    {
+      WL0Args a;
+      memset(&a, 0, sizeof(a));
+      a.gh = h->gh; a.gw = h->gw; a.W = h->cfg.width; a.row_begin = h->cfg.row_begin; a.pix0 = pix0; a.npix = h->npix;
+      a.l0tab = h->l0tab; a.sc_first = sc_first; a.KS = KS; a.n_pieces = n_pb * KS; a.P = h->Pbuf;
+      Launch L(h, K_FWD, 4.0 * WD * npx, npx * (WD * 2.0));
+      hipLaunchKernelGGL(k_wlayer0, dim3((unsigned)((a.n_pieces + 3) / 4)), dim3(256), 0, h->stream, a);
+      L.done();
+      HIPCHK(hipGetLastError());
+    }
+    for (int l = 1; l <= D - 2; ++l) {
+      WGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = reinterpret_cast<const u32x4*>(h->wf + (size_t)(l - 1) * WD * WD);
+      a.a_block_pieces = (long)blk_pieces; a.n_chunk = KS / 4;
+      a.Bin = h->Pbuf + (size_t)(l - 1) * h->p_stride; a.ks_in = KS;
+      a.bias = h->biasw + (size_t)(l - 1) * WD; a.sc = sc_hidden;
+      a.Out = h->Pbuf + (size_t)l * h->p_stride; a.ks_out = KS;
+      Launch L(h, K_FWD, 2.0 * WD * WD * npx, npx * (WD * 2.0 * (1 + NBLK)));
+      rc = launch_wgemm<0>(h, a, n_super, NBLK);
+      L.done();
+      if (rc) return rc;
+    }
+    {
+      WGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = reinterpret_cast<const u32x4*>(h->wf_last);
+      a.a_block_pieces = (long)KS; a.n_chunk = KS / 4;
+      a.Bin = h->Pbuf + (size_t)(D - 2) * h->p_stride; a.ks_in = KS;
+      a.bias = h->biasw + (size_t)(D - 2) * WD; a.sc = 1.0f / h->wscale;
+      a.img = h->img; a.pred = pred; a.gscale = (float)((double)h->gpre / (3.0 * h->n_total));
+      a.sse_part = h->sse_part + sse_off; a.Dlast = train ? h->Dlast : nullptr; a.pix0 = pix0; a.npix = h->npix;
+      sse_off += n_super;
+      Launch L(h, K_FWD, 2.0 * h->cfg.out_features * WD * npx, npx * (WD * 2.0 + 12.0 + 64.0));
+      rc = launch_wgemm<1>(h, a, n_super, 1);
+      L.done();
+      if (rc) return rc;
+    }
+    if (!train) continue;
+    // ---- backward ----
+    int n_wg = (int)(n_pb < (long)h->dw_wg ? n_pb : (long)h->dw_wg);
+    for (int l = D - 1; l >= 1; --l) {
+      const bool last = l == D - 1;
+      const u32x4* Dl = last ? h->Dlast : h->Dbuf + (size_t)l * h->p_stride;
+      const u32x4* Pprev = h->Pbuf + (size_t)(l - 1) * h->p_stride;
+      {   // weight gradient: every [256 x 256] (last layer: [32 x 256]) block in one launch, blockIdx.y = block
+        const int nby = (last ? 1 : NBLK) * NBLK;
+        int gx = h->dw_wg / nby / 8 * 8;            // multiple of 8: same-pixel workgroups share an XCD
+        if (gx < 8) gx = 8;
+        if ((long)gx > n_pb) gx = (int)n_pb;
+        WDwArgs a;
+        memset(&a, 0, sizeof(a));
+        a.D = Dl; a.ksd_total = last ? 2 : KS; a.P = Pprev; a.ksp_total = KS; a.nblk_i = NBLK;
+        a.n_pb = n_pb; a.slab = h->slab;
+        const double rows = last ? h->cfg.out_features : WD;
+        {
+          Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 2.0 * rows * WD * npx, npx * ((last ? 64.0 : WD * 2.0) + WD * 2.0));
+          const size_t lds = (size_t)4 * ((last ? 2 : 16) + 16) * 1024;
+#define SF_WDW(JWv, OPv)                                                                         \
+  do {                                                                                           \
+    rc = set_lds(k_wdw<JWv, OPv>, lds);                                                          \
+    if (rc) return rc;                                                                           \
+    hipLaunchKernelGGL((k_wdw<JWv, OPv>), dim3(gx, nby), dim3(512), lds, h->stream, a);          \
+  } while (0)
+          if (last) { if (f16) SF_WDW(32, OpF16); else SF_WDW(32, OpBF16); }
+          else { if (f16) SF_WDW(256, OpF16); else SF_WDW(256, OpBF16); }
+#undef SF_WDW
+          L.done();
+          HIPCHK(hipGetLastError());
+        }
+        WReduceArgs r;
+        memset(&r, 0, sizeof(r));
+        r.slab = h->slab; r.n_wg = gx; r.slab_rows = last ? 32 : 256; r.rows_out = last ? h->cfg.out_features : 256;
+        r.nblk_i = NBLK; r.gW = h->grads + h->off_w[l]; r.ldw = WD; r.gb = h->grads + h->off_b[l];
+        r.accumulate = c > 0; r.scale = 1.0f / h->gpre;
+        const int n = r.rows_out * 256 + r.rows_out;
+        Launch L(h, K_REDUCE, 0, (double)gx * nby * n * 4.0);
+        hipLaunchKernelGGL(k_wreduce, dim3((n + 255) / 256, nby), dim3(256), 0, h->stream, r);
+        L.done();
+        HIPCHK(hipGetLastError());
+      }
+      // data gradient: delta_{l-1} = (delta_l W_l) * omega cos(P_{l-1})
+      WGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = last ? reinterpret_cast<const u32x4*>(h->wb_last) : reinterpret_cast<const u32x4*>(h->wb + (size_t)(l - 1) * WD * WD);
+      a.a_block_pieces = last ? 32 : (long)blk_pieces; a.n_chunk = last ? 1 : KS / 4;
+      a.Bin = Dl; a.ks_in = last ? 2 : KS;
+      a.Out = h->Dbuf + (size_t)(l - 1) * h->p_stride; a.ks_out = KS; a.Pprev = Pprev;
+      const double rows = last ? h->cfg.out_features : WD;
+      Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 2.0 * rows * WD * npx,
+               npx * ((last ? 64.0 : WD * 2.0 * NBLK) + WD * 4.0));
+      rc = launch_wgemm<2>(h, a, n_super, NBLK);
+      L.done();
+      if (rc) return rc;
+    }
+    for (int jb = 0; jb < NBLK; ++jb) {   // layer 0: contraction of delta_0 with the coordinates
+      Dw0Args da;
+      memset(&da, 0, sizeof(da));
+      da.D = h->Dbuf; da.ks_total = KS; da.ks_off = 16 * jb; da.n_pb = n_pb; da.slab = h->slab; da.pix0 = pix0; da.npix = h->npix;
+      da.W = h->cfg.width; da.row_begin = h->cfg.row_begin;
+      da.inv_hm1 = h->cfg.height > 1 ? 1.0f / (float)(h->cfg.height - 1) : 0.f;
+      da.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
+      da.w_magic = ((1ULL << 40) + (unsigned long long)h->cfg.width - 1) / (unsigned long long)h->cfg.width;
+      {
+        Launch L(h, K_DW_FIRST, 4.0 * 256 * npx, 512.0 * npx);
+        const size_t lds = (size_t)8 * 16 * 1024 + 512;
+        rc = f16 ? set_lds(k_dw0<256, OpF16>, lds) : set_lds(k_dw0<256, OpBF16>, lds);
+        if (rc) return rc;
+        if (f16) hipLaunchKernelGGL((k_dw0<256, OpF16>), dim3(n_wg), dim3(512), lds, h->stream, da);
+        else hipLaunchKernelGGL((k_dw0<256, OpBF16>), dim3(n_wg), dim3(512), lds, h->stream, da);
+        L.done();
+        HIPCHK(hipGetLastError());
+      }
+      ReduceArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.slab = h->slab; ra.n_wg = n_wg; ra.accumulate = c > 0; ra.scale = 1.0f / h->gpre;
+      ra.gW = h->grads + h->off_w[0] + 512 * jb; ra.gb = h->grads + h->off_b[0] + 256 * jb;
+      ra.slab_rows = 256; ra.slab_cols = 32; ra.rows_out = 256; ra.cols_out = 2; ra.mode = 1;
+      const int n = 256 * 3;
+      Launch L(h, K_REDUCE, 0, (double)n_wg * n * 4.0);
+      hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, h->stream, ra);
+      L.done();
+      HIPCHK(hipGetLastError());
+    }
+  }
+  if (want_sse || train) {
+    Launch L(h, K_SSE, 0, (double)sse_off * 4);
+    hipLaunchKernelGGL(k_sse_reduce, dim3(1), dim3(256), 0, h->stream, (const float*)h->sse_part, (int)sse_off, h->sse_dev);
+    L.done();
+    HIPCHK(hipGetLastError());
+  }
+  return SF_OK;
+}
+
 int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
   if (!h->have_coords) return fail(SF_ERR_STATE, "sf_set_coords has not been called");
   if ((train || want_sse) && !h->img) return fail(SF_ERR_STATE, "sf_set_target has not been called");
+  if (h->wide) return run_pass_wide(h, train, pred, want_sse);
   int rc = refresh_images(h);
   if (rc) return rc;
   const int WD = h->WD, D = h->D, KS = WD / 16;
@@ -336,7 +547,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
       } else {
         Dw0Args da;
         memset(&da, 0, sizeof(da));
-        da.D = h->Dbuf; da.n_pb = n_pb; da.slab = h->slab; da.pix0 = pix0; da.npix = h->npix;
+        da.D = h->Dbuf; da.ks_total = KS; da.ks_off = 0; da.n_pb = n_pb; da.slab = h->slab; da.pix0 = pix0; da.npix = h->npix;
         da.W = h->cfg.width; da.row_begin = h->cfg.row_begin;
         da.inv_hm1 = h->cfg.height > 1 ? 1.0f / (float)(h->cfg.height - 1) : 0.f;
         da.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
@@ -395,8 +606,10 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   if (cfg->in_features != 2) return fail(SF_ERR_INVALID, "in_features must be 2 (coordinate grid)");
   if (cfg->out_features < 1 || cfg->out_features > 3) return fail(SF_ERR_INVALID, "out_features must be 1..3");
   if (cfg->depth < 2 || cfg->depth > 16) return fail(SF_ERR_INVALID, "depth must be 2..16");
-  if (cfg->hidden != 32 && cfg->hidden != 64 && cfg->hidden != 128 && cfg->hidden != 256)
-    return fail(SF_ERR_INVALID, "hidden must be 32, 64, 128 or 256 in this build");
+  if (cfg->hidden != 32 && cfg->hidden != 64 && cfg->hidden != 128 && cfg->hidden != 256 && cfg->hidden != 512 &&
+      cfg->hidden != 1024)
+    return fail(SF_ERR_INVALID, "hidden must be 32, 64, 128, 256, 512 or 1024 in this build");
+  if (cfg->hidden > 256 && cfg->depth < 3) return fail(SF_ERR_INVALID, "hidden > 256 needs depth >= 3");
   if (!cfg->outermost_linear) return fail(SF_ERR_INVALID, "outermost_linear=False is not supported");
   if (cfg->compute_dtype != SF_BF16 && cfg->compute_dtype != SF_F16)
     return fail(SF_ERR_INVALID, "compute_dtype must be SF_BF16 or SF_F16");
@@ -422,6 +635,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   }
   h->D = cfg->depth;
   h->WD = cfg->hidden;
+  h->wide = cfg->hidden > 256;
   h->stream = (hipStream_t)cfg->stream;
   h->npix = (long)(r1 - r0) * cfg->width;
   h->n_total = (double)cfg->height * (double)cfg->width;
@@ -439,7 +653,8 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   // (fp16 normal range 6e-5..65504); every gradient is multiplied back by 2^-k in the slab reduction
   if (cfg->compute_dtype == SF_F16) h->gpre = (float)exp2(ceil(log2(3.0 * (double)cfg->height * (double)cfg->width)) + 2.0);
   // chunking
-  long chunk = cfg->chunk_pixels > 0 ? cfg->chunk_pixels : (1L << 22);
+  // default: 4 Mi pixels at width <= 256 (29 GB of scratch at 256x8); the same scratch budget for wider layers
+  long chunk = cfg->chunk_pixels > 0 ? cfg->chunk_pixels : (1L << 22) / (h->wide ? cfg->hidden / 256 : 1);
   chunk = (chunk + kSuper - 1) / kSuper * kSuper;
   const long npix_pad = (h->npix + kSuper - 1) / kSuper * kSuper;
   if (chunk > npix_pad) chunk = npix_pad;
@@ -460,13 +675,19 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   ALLOC(h->params, h->P * 4); ALLOC(h->grads, h->P * 4); ALLOC(h->m, h->P * 4); ALLOC(h->v, h->P * 4);
   ALLOC(h->mask, h->P * 4);
   const size_t img_elems = (size_t)(D - 2 > 0 ? D - 2 : 1) * WD * WD;
-  ALLOC(h->wf, (size_t)(D - 2 > 0 ? D - 2 : 1) * FwdGeom(WD).PIECES * 1024); ALLOC(h->wb, img_elems * 2);
-  ALLOC(h->wf_last, (size_t)(WD / 16 + 1) * 1024); ALLOC(h->wb_last, (size_t)WD / 32 * 64 * 16);
+  if (h->wide) {   // blocked images of siren_wide.hip
+    ALLOC(h->wf, img_elems * 2); ALLOC(h->wb, img_elems * 2);
+    ALLOC(h->wf_last, (size_t)(WD / 16) * 1024); ALLOC(h->wb_last, (size_t)(WD / 256) * 32 * 1024);
+    ALLOC(h->biasw, ((size_t)(D - 2) * WD + 32) * 4);
+  } else {
+    ALLOC(h->wf, (size_t)(D - 2 > 0 ? D - 2 : 1) * FwdGeom(WD).PIECES * 1024); ALLOC(h->wb, img_elems * 2);
+    ALLOC(h->wf_last, (size_t)(WD / 16 + 1) * 1024); ALLOC(h->wb_last, (size_t)WD / 32 * 64 * 16);
+  }
   ALLOC(h->l0tab, (size_t)WD * 16);
   ALLOC(h->gh, (size_t)cfg->height * 4); ALLOC(h->gw, (size_t)cfg->width * 4);
   ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->p_stride * 16);
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
-  ALLOC(h->slab, (size_t)h->dw_wg * ((size_t)WD * WD + WD) * 4);
+  { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4); }
   h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
   ALLOC(h->sse_part, h->n_sse * 4); ALLOC(h->sse_dev, 8);
 #undef ALLOC
@@ -484,7 +705,7 @@ int sf_destroy(sf_handle* h) {
   if (h->stream || true) hipStreamSynchronize(h->stream);
   for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab,
-                  h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part,
+                  h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part, h->biasw,
                   h->sse_dev};
   for (void* p : ptrs) if (p) hipFree(p);
   delete h;

@@ -629,7 +629,8 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
 //   kernel touches HBM for delta_0 only.  One 32-row tile of the slab per wave.
 // ---------------------------------------------------------------------------------------------
 struct Dw0Args {
-  const u32x4* D;       // delta image of layer 0 (JW/16 k-steps per pixel block)
+  const u32x4* D;       // delta image of layer 0 (ks_total k-steps per pixel block; this launch reads JW/16 from ks_off)
+  int ks_total, ks_off; // ks_total = JW/16, ks_off = 0 unless the layer is wider than one launch covers (siren_wide.hip)
   long n_pb;
   float* slab;          // [gridDim.x][JW*32 + JW]
   long pix0, npix;
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(JW * 2) void k_dw0(Dw0Args a) {
   auto stage = [&](int k) {
     char* base = smem + (k % NB) * BLK;
     const long pb = pb_begin + k * pb_step;
-    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * KSJ + pc) * 64 + lane, base + pc * 1024);
+    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * a.ks_total + a.ks_off + pc) * 64 + lane, base + pc * 1024);
   };
   // B operand = coordinates of the block's 32 pixels as 16-bit columns {x0_hi, x0_lo, x1_hi, x1_lo}.  Wave 0
   // builds a [4][32] table per block (one pixel per lane, one integer division), double-buffered by block

@@ -1,0 +1,389 @@
+// siren_wide.hip — layer-at-a-time kernels for hidden widths above 256 (512, 1024: BASELINE configs 3 and 5).
+//
+// The fused kernels of siren_kernels.hip keep a whole activation vector per pixel in registers and a
+// whole 256x256 weight gradient per workgroup; neither fits beyond width 256.  Wide networks therefore run
+// layer by layer with the activations (phases) and deltas in HBM, still in F-layout, through three kernels:
+//   k_wlayer0   phases of layer 0 from the coordinates (elementwise)
+//   k_wgemm     Out^T[256-neuron block x 32 pixels per wave] = A-block * B, A (weights) streamed through an
+//               LDS ring by LDS-DMA, B (input pieces) read from HBM/L2.  MODE 0: forward hidden layer
+//               (B = sin(phase), epilogue -> phase), MODE 1: forward last layer + residual/loss,
+//               MODE 2: backward data (B = delta, epilogue x cos(phase) -> delta)
+//   k_wdw       weight gradient of one 256x256 (or 32x256) block: delta^T * sin(phase), the W phase of k_bwd
+// Arithmetic intensity grows with the width (FLOPs ~ W^2, bytes ~ W), so this path is less HBM-starved than
+// the width-256 one even without fusion.  Reference arithmetic: same lines as siren_kernels.hip.
+#pragma once
+
+namespace sf {
+
+// ---------------------------------------------------------------------------------------------------------
+// blocked A image: [ob][chunk c][tile ot][s4][lane][8] ; chunk = 4 k-steps ; OT tiles of 32 rows per block
+// element (ob, c, ot, s4, lane=(r,h), j) = M[(ob*OT + ot)*32 + r][16*(4c + s4) + PI(h, j)] * scale   (0 outside)
+// with M = W (forward) or W^T (backward).
+// ---------------------------------------------------------------------------------------------------------
+struct WImgArgs {
+  const float* W;       // [rows][cols] row-major fp32 master weights of one layer
+  int rows, cols;       // nn.Linear layout: rows = out features, cols = in features
+  int transpose;        // 0: M = W (M rows = out), 1: M = W^T (M rows = in)
+  int OT;               // tiles per output block (8, or 1 for the 32-row padded last layer forward)
+  int n_ob, n_chunk;    // output blocks, K chunks
+  float scale;
+  int f16;
+  uint16_t* dst;
+};
+__global__ void k_wimage(WImgArgs a) {
+  const long total = (long)a.n_ob * a.n_chunk * a.OT * 4 * 512;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  long e = gid;
+  const int j = e & 7; e >>= 3;
+  const int lane = e & 63; e >>= 6;
+  const int s4 = e & 3; e >>= 2;
+  const int ot = (int)(e % a.OT); e /= a.OT;
+  const int c = (int)(e % a.n_chunk);
+  const int ob = (int)(e / a.n_chunk);
+  const int r = lane & 31, h = lane >> 5;
+  const int mrow = (ob * a.OT + ot) * 32 + r, mk = 16 * (4 * c + s4) + pi_perm(h, j);
+  const int mrows = a.transpose ? a.cols : a.rows, mcols = a.transpose ? a.rows : a.cols;
+  float v = 0.f;
+  if (mrow < mrows && mk < mcols) v = (a.transpose ? a.W[(long)mk * a.cols + mrow] : a.W[(long)mrow * a.cols + mk]) * a.scale;
+  a.dst[gid] = a.f16 ? to_f16(v) : to_bf16(v);
+}
+
+// layer-0 table {w00, w01, b0, 0} per neuron and the pre-scaled fp32 biases of the hidden layers 1..D-2
+// ([D-2][WD]) followed by the last layer's padded to 32
+struct WTabArgs {
+  const float* params; int depth, WD, out_features; long off_w0, off_b0; long off_b[16]; float wscale;
+  f32x4* l0tab; float* bias;
+};
+__global__ void k_wtables(WTabArgs a) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < a.WD) {
+    const float* W0 = a.params + a.off_w0;
+    a.l0tab[gid] = f32x4{W0[gid * 2], W0[gid * 2 + 1], a.params[a.off_b0 + gid], 0.f};
+  }
+  const long nh = (long)(a.depth - 2) * a.WD;
+  if (gid < nh) {
+    const int l = (int)(gid / a.WD) + 1, n = (int)(gid % a.WD);
+    a.bias[gid] = a.params[a.off_b[l] + n] * a.wscale;
+  }
+  if (gid < 32) a.bias[nh + gid] = gid < a.out_features ? a.params[a.off_b[a.depth - 1] + gid] * a.wscale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_wlayer0: P_0 piece (pb, s) for every pixel block: phase of sin(omega0 * (W0 x + b0))
+// ---------------------------------------------------------------------------------------------------------
+struct WL0Args {
+  const float* gh; const float* gw; int W, row_begin; long pix0, npix;
+  const f32x4* l0tab; float sc_first; int KS; long n_pieces; u32x4* P;
+};
+__global__ __launch_bounds__(256) void k_wlayer0(WL0Args a) {
+  const long piece = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (piece >= a.n_pieces) return;
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const long pb = piece / a.KS;
+  const int s = (int)(piece % a.KS);
+  long pix = a.pix0 + pb * 32 + m;
+  if (pix >= a.npix) pix = a.npix - 1;
+  const int row = (int)(pix / a.W), col = (int)(pix - (long)row * a.W);
+  const float x0 = (a.gh[a.row_begin + row] - 0.5f) * 2.0f, x1 = (a.gw[col] - 0.5f) * 2.0f;
+  float ph[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const f32x4 t = a.l0tab[16 * s + pi_perm(h, j)];
+    ph[j] = __builtin_amdgcn_fractf(__builtin_fmaf(t.y, x1, __builtin_fmaf(t.x, x0, t.z)) * a.sc_first);
+  }
+  a.P[piece * 64 + lane] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
+                                 pack_phase2(ph[6], ph[7])};
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_wgemm
+// ---------------------------------------------------------------------------------------------------------
+struct WGemmArgs {
+  const u32x4* A;        // blocked image of this layer: block ob at A + ob * a_block_pieces * 64
+  long a_block_pieces;   // pieces per output block = n_chunk * OT * 4
+  int n_chunk;           // K chunks of 4 k-steps
+  const u32x4* Bin;      // input tensor (F-layout, ks_in k-steps per pixel block): phases (MODE 0/1) or deltas (MODE 2)
+  int ks_in;
+  const float* bias;     // MODE 0/1: [out rows], pre-scaled; nullptr otherwise
+  float sc;              // MODE 0: omega/(2 pi)/wscale ; MODE 1: 1/wscale ; MODE 2: unused
+  u32x4* Out;            // MODE 0: phases out, MODE 2: deltas out (F-layout, ks_out k-steps per block)
+  int ks_out;
+  const u32x4* Pprev;    // MODE 2: phases of the layer whose delta is produced (same geometry as Out)
+  // MODE 1 (last layer)
+  const float* img; float* pred; float gscale; float* sse_part; u32x4* Dlast; long pix0, npix;
+};
+
+template <int MODE, typename OP>
+__global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
+  constexpr int OT = MODE == 1 ? 1 : 8;
+  constexpr int NB = 4, CH = OT * 4 * 1024;   // ring slots, bytes per chunk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sRed = reinterpret_cast<float*>(smem + NB * CH);
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ob = blockIdx.y;
+  const long pb = (long)blockIdx.x * kWavesFwd + wave;
+  const u32x4* Ablk = a.A + (size_t)ob * a.a_block_pieces * 64;
+  auto stage = [&](int c) {
+    char* base = smem + (c % NB) * CH;
+    for (int pc = wave; pc < OT * 4; pc += kWavesFwd) glds16(Ablk + ((size_t)c * OT * 4 + pc) * 64 + lane, base + pc * 1024);
+  };
+  f32x16 acc[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    if (MODE != 2) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&a.bias[(ob * OT + ot) * 32 + 8 * q4 + 4 * h]);
+        acc[ot][4 * q4 + 0] = b.x; acc[ot][4 * q4 + 1] = b.y; acc[ot][4 * q4 + 2] = b.z; acc[ot][4 * q4 + 3] = b.w;
+      }
+    } else {
+      acc[ot] = f32x16{};
+    }
+  }
+  float tgt[3] = {0.f, 0.f, 0.f};
+  const long pix = a.pix0 + pb * 32 + m;
+  const bool valid = MODE == 1 && pix < a.npix;
+  if (MODE == 1 && a.img && h == 0 && valid) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tgt[c] = a.img[pix * 3 + c];
+  }
+  asm volatile("" ::"v"(tgt[0]), "v"(tgt[1]), "v"(tgt[2]), "v"(acc[0][0]));
+  // B pieces (raw phases / deltas) are prefetched TWO chunks ahead into registers, right behind the LDS-DMA of
+  // the same chunk: vmcnt counts both in issue order, so "everything but the youngest G + 4 operations" at the
+  // top of a step means chunk c (A in LDS, B in registers) has landed while chunk c+1 stays in flight.
+  constexpr int G = OT * 4 / kWavesFwd;      // LDS-DMA instructions per wave per chunk (0: uneven -> full waits)
+  auto load_b = [&](int c, u32x4 (&raw)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int sidx = 4 * c + i;
+      sidx = sidx < a.ks_in ? sidx : a.ks_in - 1;
+      raw[i] = a.Bin[(pb * a.ks_in + sidx) * 64 + lane];
+    }
+  };
+  u32x4 r0[4], r1[4], r2[4];
+  stage(0);
+  load_b(0, r0);
+  if (a.n_chunk > 1) { stage(1); load_b(1, r1); }
+  for (int c = 0; c < a.n_chunk; ++c) {
+    if (G > 0 && c + 1 < a.n_chunk) bar_dma<G + 4>(); else bar_all();
+    if (c + 2 < a.n_chunk) { stage(c + 2); load_b(c + 2, r2); }
+    asm volatile("" ::: "memory");
+    u32x4 b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 v = r0[i];
+      if (MODE != 2) {   // phases -> activations
+        u32x4 o;
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2)
+          o[j2] = OP::pack2(__builtin_amdgcn_sinf(phase_rev_lo(v[j2])), __builtin_amdgcn_sinf(phase_rev_hi(v[j2])));
+        v = o;
+      }
+      b[i] = 4 * c + i < a.ks_in ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+    const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * CH) + lane;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[ot] = OP::mfma(sA[(ot * 4 + i) * 64], b[i], acc[ot]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r0[i] = r1[i]; r1[i] = r2[i]; }
+  }
+  // ---- epilogues ----
+  if (MODE == 0) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float ph[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ph[j] = __builtin_amdgcn_fractf(acc[ot][8 * q + j] * a.sc);
+        a.Out[(pb * a.ks_out + 16 * ob + 2 * ot + q) * 64 + lane] =
+            u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]), pack_phase2(ph[6], ph[7])};
+      }
+  } else if (MODE == 2) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const long pidx = (pb * a.ks_out + 16 * ob + 2 * ot + q) * 64 + lane;
+        const u32x4 p = a.Pprev[pidx];
+        u32x4 o;
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2)
+          o[j2] = OP::pack2(acc[ot][8 * q + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(p[j2])),
+                            acc[ot][8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(p[j2])));
+        a.Out[pidx] = o;
+      }
+  } else {
+    float sse = 0.f, d[3] = {0.f, 0.f, 0.f};
+    if (h == 0 && valid) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float p = acc[0][c] * a.sc * 0.5f + 0.5f;
+        if (a.pred) a.pred[pix * 3 + c] = p;
+        if (a.img) {
+          const float r = p - tgt[c];
+          sse += r * r;
+          d[c] = r * a.gscale;
+        }
+      }
+    }
+    if (a.Dlast) {
+      a.Dlast[(pb * 2 + 0) * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
+      a.Dlast[(pb * 2 + 1) * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
+    if (lane == 0) sRed[wave] = sse;
+    __syncthreads();
+    if (tid == 0 && a.sse_part) {
+      float t = 0.f;
+      for (int w = 0; w < kWavesFwd; ++w) t += sRed[w];
+      a.sse_part[blockIdx.x] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_wdw: one [JW x 256] block of a weight gradient: dW[jb-block][ib-block] = delta[:, jb]^T * sin(phase[:, ib])
+//   ring of 32-pixel blocks as in k_bwd; the phase pieces are converted to activations in place by the waves
+//   (no X phase here), then both operands are read transposed.
+// ---------------------------------------------------------------------------------------------------------
+struct WDwArgs {
+  const u32x4* D; int ksd_total;            // delta tensor of layer l: k-steps per pixel block
+  const u32x4* P; int ksp_total;            // phase tensor of layer l-1
+  int nblk_i;                               // 256-column blocks of the phase tensor: blockIdx.y = jb * nblk_i + ib
+  long n_pb;
+  float* slab;                              // [gridDim.y][gridDim.x][JW*256 + JW]
+};
+
+template <int JW, typename OP>
+__global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
+  constexpr int WAVES_R = JW == 256 ? 2 : 1, WAVES_C = 8 / WAVES_R, NW = 8;
+  constexpr int JT = JW / 32, IT = 8, WJ = JT / WAVES_R, WI = IT / WAVES_C;
+  constexpr int KSJ = JW / 16, KSI = 16, NB = 4, PD = 3, BLK = (KSJ + KSI) * 1024;
+  constexpr int G = KSJ % NW == 0 ? KSJ / NW + KSI / NW : 0;   // LDS-DMA instructions per wave per block (0: uneven)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WAVES_C, wc = wave % WAVES_C;
+  // all blocks of one layer run in ONE launch; workgroups with the same blockIdx.x stream the same pixel blocks
+  // (of different column blocks) at the same time and sit on the same XCD (gridDim.x is a multiple of 8), so
+  // each delta / phase piece is pulled from HBM once and served to the other readers by that XCD's L2
+  const int jb = blockIdx.y / a.nblk_i, ib = blockIdx.y % a.nblk_i;
+  const int ksd_off = 16 * jb, ksp_off = 16 * ib;
+  const long pb_begin = blockIdx.x, pb_step = gridDim.x;
+  const int nblk = (int)((a.n_pb - pb_begin + pb_step - 1) / pb_step);
+  f32x16 acc[WJ][WI];
+#pragma unroll
+  for (int x = 0; x < WJ; ++x)
+#pragma unroll
+    for (int y = 0; y < WI; ++y) acc[x][y] = f32x16{};
+  float dbs[WJ];
+#pragma unroll
+  for (int x = 0; x < WJ; ++x) dbs[x] = 0.f;
+  auto stage = [&](int k) {
+    char* base = smem + (k % NB) * BLK;
+    const long pb = pb_begin + k * pb_step;
+    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * a.ksd_total + ksd_off + pc) * 64 + lane, base + pc * 1024);
+    for (int pc = wave; pc < KSI; pc += NW) glds16(a.P + (pb * a.ksp_total + ksp_off + pc) * 64 + lane, base + (KSJ + pc) * 1024);
+  };
+  for (int k = 0; k < PD && k < nblk; ++k) stage(k);
+  for (int k = 0; k < nblk; ++k) {
+    // block k landed (blocks k+1, k+2 stay in flight), everyone finished block k-1 (whose slot is refilled next)
+    if (G > 0 && k + PD - 1 < nblk) bar_dma<(PD - 1) * G>(); else bar_all();
+    if (k + PD < nblk) stage(k + PD);
+    asm volatile("" ::: "memory");
+    char* sD = smem + (k % NB) * BLK;
+    char* sP = sD + KSJ * 1024;
+    for (int pc = wave; pc < KSI; pc += NW) {      // phases -> activations, in place
+      u32x4* pp = reinterpret_cast<u32x4*>(sP + pc * 1024) + lane;
+      const u32x4 p = *pp;
+      u32x4 o;
+#pragma unroll
+      for (int j2 = 0; j2 < 4; ++j2)
+        o[j2] = OP::pack2(__builtin_amdgcn_sinf(phase_rev_lo(p[j2])), __builtin_amdgcn_sinf(phase_rev_hi(p[j2])));
+      *pp = o;
+    }
+    bar_lds();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 fa[WJ], fb[WI];
+#pragma unroll
+      for (int x = 0; x < WJ; ++x)
+        fa[x] = ds_read_tr_pair(sD, tr_addr(wr * WJ + x, kk, 0, lane), tr_addr(wr * WJ + x, kk, 1, lane));
+#pragma unroll
+      for (int y = 0; y < WI; ++y)
+        fb[y] = ds_read_tr_pair(sP, tr_addr(wc * WI + y, kk, 0, lane), tr_addr(wc * WI + y, kk, 1, lane));
+#pragma unroll
+      for (int x = 0; x < WJ; ++x)
+#pragma unroll
+        for (int y = 0; y < WI; ++y) acc[x][y] = OP::mfma(fa[x], fb[y], acc[x][y]);
+      if (wc == 0) {
+#pragma unroll
+        for (int x = 0; x < WJ; ++x) {
+          float t = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t += OP::sum2(fa[x][e]);
+          dbs[x] += t;
+        }
+      }
+    }
+  }
+  float* slab = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (JW * 256 + JW);
+  const int cl = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int x = 0; x < WJ; ++x)
+#pragma unroll
+    for (int y = 0; y < WI; ++y)
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        slab[(size_t)(32 * (wr * WJ + x) + rho(t, hh)) * 256 + 32 * (wc * WI + y) + cl] = acc[x][y][t];
+  if (wc == 0) {
+#pragma unroll
+    for (int x = 0; x < WJ; ++x) {
+      const float tsum = dbs[x] + __shfl_xor(dbs[x], 32);
+      if (hh == 0) slab[JW * 256 + 32 * (wr * WJ + x) + cl] = tsum;
+    }
+  }
+}
+
+// block-wise slab reduction into a sub-block of a [rows_total x ldw] gradient matrix (fixed order)
+struct WReduceArgs {
+  const float* slab; int n_wg, slab_rows;       // slab = [gridDim.y blocks][n_wg][slab_rows*256 + slab_rows]
+  int rows_out;                                 // valid rows of a block (256, or out_features for the last layer)
+  int nblk_i;                                   // blockIdx.y = jb * nblk_i + ib
+  float* gW; int ldw;                           // gradient matrix [rows][ldw]; block (jb, ib) starts at [256 jb][256 ib]
+  float* gb;                                    // bias gradient (taken from the ib == 0 blocks)
+  int accumulate; float scale;
+};
+__global__ void k_wreduce(WReduceArgs a) {
+  const long slab_sz = (long)a.slab_rows * 256 + a.slab_rows;
+  const int jb = blockIdx.y / a.nblk_i, ib = blockIdx.y % a.nblk_i;
+  const float* slab = a.slab + (size_t)blockIdx.y * a.n_wg * slab_sz;
+  const int nW = a.rows_out * 256;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nW + (ib == 0 ? a.rows_out : 0)) return;
+  if (idx < nW) {
+    const int j = idx >> 8, i = idx & 255;
+    const float* p = slab + (long)j * 256 + i;
+    float s = 0.f;
+    for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz];
+    s *= a.scale;
+    float* o = a.gW + (long)(256 * jb + j) * a.ldw + 256 * ib + i;
+    *o = a.accumulate ? *o + s : s;
+  } else {
+    const int j = idx - nW;
+    const float* p = slab + (long)a.slab_rows * 256 + j;
+    float s = 0.f;
+    for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz];
+    s *= a.scale;
+    float* o = a.gb + 256 * jb + j;
+    *o = a.accumulate ? *o + s : s;
+  }
+}
+
+}  // namespace sf

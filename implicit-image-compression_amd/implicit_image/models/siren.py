@@ -62,12 +62,15 @@ class Siren(nn.Module):
         # fills with per-Linear forward-pre and backward hooks (k-means quantisation, pipeline/quant/kmeans.py:39-55)
         self.pre_pass_callbacks = []
         self.post_backward_callbacks = []
-        # hidden widths the kernels are instantiated for; any other width <= 256 (e.g. Small_Dense's
-        # int(hidden * sqrt(density)), reference siren.py:88) runs zero-padded to the next one: padded neurons
-        # have zero weights and bias, output sin(0) = 0 and receive exactly zero gradients, so they stay zero
-        self._engine_width = next((w for w in (32, 64, 128, 256) if w >= hidden_size), None)
+        # hidden widths the kernels are instantiated for (<= 256: fused chain kernels; 512 / 1024: layer-at-a-time
+        # kernels); any other width (e.g. Small_Dense's int(hidden * sqrt(density)), reference siren.py:88) runs
+        # zero-padded to the next one: padded neurons have zero weights and bias, output sin(0) = 0 and receive
+        # exactly zero gradients, so they stay zero
+        self._engine_width = next((w for w in (32, 64, 128, 256, 512, 1024) if w >= hidden_size), None)
         if self._engine_width is None:
-            raise NotImplementedError(f"hidden_size {hidden_size} > 256 is not supported by the gfx950 engine yet")
+            raise NotImplementedError(f"hidden_size {hidden_size} > 1024 is not supported by the gfx950 engine")
+        if self._engine_width > 256 and depth < 3:
+            raise NotImplementedError("hidden_size > 256 needs depth >= 3")
         self._padded = self._engine_width != hidden_size
         self._pad_index = None
         self._engine = None

@@ -376,3 +376,72 @@ def test_small_dense_width_runs_zero_padded():
     _, _, psnr, _ = eval_epoch(model, grid.cuda(), img.cuda())
     _, _, psnr_ref, _ = so.eval_epoch(p, so.get_grid(H, W), img)
     assert abs(psnr - psnr_ref) <= 0.05
+
+
+# ---- wide path (hidden 512 / 1024: layer-at-a-time kernels, BASELINE configs 3 and 5) -------------------
+@pytest.mark.parametrize("dtype,tol,gtol", [("f16", 3e-4, 5e-3), ("bf16", 3e-3, 3e-2)])
+def test_wide_512_forward_and_gradients_vs_reference_golden(golden, dtype, tol, gtol):
+    d = golden("wide_512x3_32")
+    H, W, _ = d["img"].shape
+    p = so.unflatten(d["init"], 512, 3)
+    eng = _engine(H, W, 512, 3, dtype, p, torch.tensor(d["img"]))
+    pred, sse = eng.forward()
+    assert np.abs(pred.cpu().numpy() - d["pred"]).max() <= tol
+    assert abs(sse / (3 * H * W) - float(d["loss"])) <= 50 * tol * float(d["loss"])
+    eng.forward_backward()
+    g, ref = eng.get_grads().cpu().numpy(), d["grads"]
+    assert np.linalg.norm(g - ref) <= gtol * np.linalg.norm(ref)
+    off = 0
+    for fin, fout in so.layer_dims(512, 3):
+        for n in (fin * fout, fout):
+            a, b = g[off:off + n], ref[off:off + n]
+            off += n
+            assert np.linalg.norm(a - b) <= gtol * np.linalg.norm(b), (fin, fout, n)
+    if dtype == "f16":   # 10 Adam steps against the reference's loss curve (before trajectories decorrelate)
+        eng.set_params(torch.tensor(d["init"]).cuda())
+        losses = np.array(eng.step([3e-4] * 10, want_loss=True))
+        assert np.abs(losses / d["losses"] - 1).max() <= 2e-2
+
+
+@pytest.mark.parametrize("H,W,hidden,depth,chunk", [(40, 52, 512, 5, 0), (9, 33, 1024, 3, 0), (48, 48, 1024, 4, 1024),
+                                                     (1, 1, 512, 3, 0)])
+def test_wide_vs_oracle(H, W, hidden, depth, chunk):
+    """gradients of every layer against the fp32 oracle (itself pinned to the reference at 512x3), incl. ragged
+    grids and a multi-chunk pass; tolerances as for the narrow widths (fp16 operands)."""
+    p = so.siren_init(hidden, depth, seed=3)
+    img = so.synthetic_image(H, W, seed=5)
+    eng = _engine(H, W, hidden, depth, "f16", p, img, chunk_pixels=chunk)
+    grid = so.get_grid(H, W)
+    pred, sse = eng.forward()
+    assert np.abs(pred.cpu().numpy() - so.forward(p, grid).numpy()).max() <= 5e-4
+    loss, sse_ref, grads = so.loss_and_grads(p, grid, img)
+    assert abs(sse - sse_ref) <= 2e-3 * sse_ref
+    eng.forward_backward()
+    g, ref = eng.get_grads().cpu().numpy(), so.flatten(grads)
+    off = 0
+    for fin, fout in so.layer_dims(hidden, depth):
+        for n in (fin * fout, fout):
+            a, b = g[off:off + n], ref[off:off + n]
+            off += n
+            assert np.linalg.norm(a - b) <= 6e-3 * np.linalg.norm(b) + 1e-12, (fin, fout, n)
+
+
+def test_wide_host_mirror_padded_width():
+    """Siren(hidden_size=300) runs zero-padded on the 512-wide kernels; one train_epoch equals the oracle's."""
+    from implicit_image.models import Siren
+    from implicit_image.utils import train_helper as th
+    from implicit_image.data import get_grid
+    torch.manual_seed(0)
+    m = Siren(depth=3, hidden_size=300, first_omega_0=50.0, hidden_omega_0=30.0).cuda()
+    p = [q.detach().cpu().clone() for q in m._param_list()]
+    H, W = 24, 40
+    img = so.synthetic_image(H, W, seed=2)
+    grid = get_grid(H, W).cuda()
+    optim, sched = th.get_optimizer_lr_scheduler(m, dict(name="adam", lr=3e-4))
+    loss = th.train_epoch(m, optim, grid, img.cuda(), lr_scheduler=sched)
+    opt = so.Adam(p)
+    ref = so.train_epoch(p, opt, so.get_grid(H, W), img, 0)
+    assert abs(loss - ref) <= 2e-3 * ref
+    m.download_params()
+    for a, b in zip(m._param_list(), p):
+        assert (a.detach().cpu() - b).abs().max() <= 6.2e-4   # one Adam step moves <= lr; sign flips on ~0 gradients

@@ -16,12 +16,14 @@ def test_grid_matches_reference(golden):
 
 
 def test_init_draw_order_bit_exact(golden):
-    for name, hidden, depth in (("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8), ("grads_128x6_48", 128, 6)):
+    for name, hidden, depth in (("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8), ("grads_128x6_48", 128, 6),
+                                ("wide_512x3_32", 512, 3)):
         assert np.array_equal(so.flatten(so.siren_init(hidden, depth, seed=0)), golden(name)["init"])
 
 
 def test_first_step_loss_and_gradients(golden):
-    for name, hidden, depth in (("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8), ("grads_128x6_48", 128, 6)):
+    for name, hidden, depth in (("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8), ("grads_128x6_48", 128, 6),
+                                ("wide_512x3_32", 512, 3)):
         d = golden(name)
         p = so.unflatten(d["init"], hidden, depth)
         H, W, _ = d["img"].shape
@@ -31,6 +33,17 @@ def test_first_step_loss_and_gradients(golden):
         g = so.flatten(grads)
         assert np.linalg.norm(g - d["grads"]) <= 2e-6 * np.linalg.norm(d["grads"])   # fp32 summation-order noise
         assert np.abs(so.forward(p, grid).numpy() - d["pred"]).max() <= 2e-6
+
+
+def test_wide_short_run(golden):
+    """512x3 (wide path fixture): 10 Adam steps of the oracle against the reference's loss curve."""
+    d = golden("wide_512x3_32")
+    H, W, _ = d["img"].shape
+    p = so.unflatten(d["init"], 512, 3)
+    opt = so.Adam(p)
+    grid, img = so.get_grid(H, W), torch.tensor(d["img"])
+    losses = np.array([so.train_epoch(p, opt, grid, img, t) for t in range(10)])
+    assert np.abs(losses / d["losses"] - 1).max() <= 1e-3
 
 
 def test_config1_training_run(golden):
