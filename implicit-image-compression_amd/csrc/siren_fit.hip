@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -68,11 +69,23 @@ struct sf_engine {
   long chunk_px = 0;
   long p_stride = 0;  // pieces per layer
   u32x4 *Pbuf = nullptr, *Dbuf = nullptr, *Dlast = nullptr;
+  u32x4* Abuf = nullptr;   // wide path: activations sin(phase) of every hidden layer (16-bit float, F-layout)
   float* slab = nullptr;
   int dw_wg = 0;
   float* sse_part = nullptr;
   long n_sse = 0;
   double* sse_dev = nullptr;
+  // graph replay of whole training steps (sf_step): small fits are bound by launch latency, not by the kernels
+  hipStream_t gstream = nullptr;
+  hipEvent_t gev_in = nullptr, gev_out = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  const float* g_img = nullptr;
+  bool g_mask = false;
+  bool replay = false;      // launches issued now belong to a replayed step: per-step scalars come from device tables
+  float* step_tab = nullptr;
+  double* loss_tab = nullptr;
+  int* iter_dev = nullptr;
+  int tab_cap = 0;
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -308,8 +321,11 @@ int launch_wgemm(sf_engine* h, const WGemmArgs& a, int n_super, int n_ob) {
   const bool f16 = h->cfg.compute_dtype == SF_F16;
   int rc = f16 ? set_lds(k_wgemm<MODE, OpF16>, lds) : set_lds(k_wgemm<MODE, OpBF16>, lds);
   if (rc) return rc;
-  if (f16) hipLaunchKernelGGL((k_wgemm<MODE, OpF16>), dim3(n_super, n_ob), dim3(512), lds, h->stream, a);
-  else hipLaunchKernelGGL((k_wgemm<MODE, OpBF16>), dim3(n_super, n_ob), dim3(512), lds, h->stream, a);
+  WGemmArgs b = a;
+  b.n_super = n_super; b.n_ob = n_ob;
+  const unsigned grid = (unsigned)((n_super + 7) / 8 * 8 * n_ob);
+  if (f16) hipLaunchKernelGGL((k_wgemm<MODE, OpF16>), dim3(grid), dim3(512), lds, h->stream, b);
+  else hipLaunchKernelGGL((k_wgemm<MODE, OpBF16>), dim3(grid), dim3(512), lds, h->stream, b);
   HIPCHK(hipGetLastError());
   return SF_OK;
 }
@@ -336,9 +352,10 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       WL0Args a;
       memset(&a, 0, sizeof(a));
       a.gh = h->gh; a.gw = h->gw; a.W = h->cfg.width; a.row_begin = h->cfg.row_begin; a.pix0 = pix0; a.npix = h->npix;
-      a.l0tab = h->l0tab; a.sc_first = sc_first; a.KS = KS; a.n_pieces = n_pb * KS; a.P = h->Pbuf;
-      Launch L(h, K_FWD, 4.0 * WD * npx, npx * (WD * 2.0));
-      hipLaunchKernelGGL(k_wlayer0, dim3((unsigned)((a.n_pieces + 3) / 4)), dim3(256), 0, h->stream, a);
+      a.l0tab = h->l0tab; a.sc_first = sc_first; a.KS = KS; a.n_pieces = n_pb * KS; a.P = h->Pbuf; a.Act = h->Abuf;
+      Launch L(h, K_FWD, 4.0 * WD * npx, npx * (WD * 4.0));
+      if (f16) hipLaunchKernelGGL(k_wlayer0<OpF16>, dim3((unsigned)((a.n_pieces + 3) / 4)), dim3(256), 0, h->stream, a);
+      else hipLaunchKernelGGL(k_wlayer0<OpBF16>, dim3((unsigned)((a.n_pieces + 3) / 4)), dim3(256), 0, h->stream, a);
       L.done();
       HIPCHK(hipGetLastError());
     }
@@ -347,10 +364,10 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       memset(&a, 0, sizeof(a));
       a.A = reinterpret_cast<const u32x4*>(h->wf + (size_t)(l - 1) * WD * WD);
       a.a_block_pieces = (long)blk_pieces; a.n_chunk = KS / 4;
-      a.Bin = h->Pbuf + (size_t)(l - 1) * h->p_stride; a.ks_in = KS;
+      a.Bin = h->Abuf + (size_t)(l - 1) * h->p_stride; a.ks_in = KS;
       a.bias = h->biasw + (size_t)(l - 1) * WD; a.sc = sc_hidden;
-      a.Out = h->Pbuf + (size_t)l * h->p_stride; a.ks_out = KS;
-      Launch L(h, K_FWD, 2.0 * WD * WD * npx, npx * (WD * 2.0 * (1 + NBLK)));
+      a.Out = h->Pbuf + (size_t)l * h->p_stride; a.OutAct = h->Abuf + (size_t)l * h->p_stride; a.ks_out = KS;
+      Launch L(h, K_FWD, 2.0 * WD * WD * npx, npx * (WD * 2.0 * (2 + NBLK)));
       rc = launch_wgemm<0>(h, a, n_super, NBLK);
       L.done();
       if (rc) return rc;
@@ -360,7 +377,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       memset(&a, 0, sizeof(a));
       a.A = reinterpret_cast<const u32x4*>(h->wf_last);
       a.a_block_pieces = (long)KS; a.n_chunk = KS / 4;
-      a.Bin = h->Pbuf + (size_t)(D - 2) * h->p_stride; a.ks_in = KS;
+      a.Bin = h->Abuf + (size_t)(D - 2) * h->p_stride; a.ks_in = KS;
       a.bias = h->biasw + (size_t)(D - 2) * WD; a.sc = 1.0f / h->wscale;
       a.img = h->img; a.pred = pred; a.gscale = (float)((double)h->gpre / (3.0 * h->n_total));
       a.sse_part = h->sse_part + sse_off; a.Dlast = train ? h->Dlast : nullptr; a.pix0 = pix0; a.npix = h->npix;
@@ -384,7 +401,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
         if ((long)gx > n_pb) gx = (int)n_pb;
         WDwArgs a;
         memset(&a, 0, sizeof(a));
-        a.D = Dl; a.ksd_total = last ? 2 : KS; a.P = Pprev; a.ksp_total = KS; a.nblk_i = NBLK;
+        a.D = Dl; a.ksd_total = last ? 2 : KS; a.P = h->Abuf + (size_t)(l - 1) * h->p_stride; a.ksp_total = KS; a.nblk_i = NBLK;
         a.n_pb = n_pb; a.slab = h->slab;
         const double rows = last ? h->cfg.out_features : WD;
         {
@@ -452,14 +469,15 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       ra.slab_rows = 256; ra.slab_cols = 32; ra.rows_out = 256; ra.cols_out = 2; ra.mode = 1;
       const int n = 256 * 3;
       Launch L(h, K_REDUCE, 0, (double)n_wg * n * 4.0);
-      hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, h->stream, ra);
+      hipLaunchKernelGGL(k_reduce, dim3((n + 15) / 16), dim3(256), 0, h->stream, ra);
       L.done();
       HIPCHK(hipGetLastError());
     }
   }
   if (want_sse || train) {
     Launch L(h, K_SSE, 0, (double)sse_off * 4);
-    hipLaunchKernelGGL(k_sse_reduce, dim3(1), dim3(256), 0, h->stream, (const float*)h->sse_part, (int)sse_off, h->sse_dev);
+    hipLaunchKernelGGL(k_sse_reduce, dim3(1), dim3(256), 0, h->stream, (const float*)h->sse_part, (int)sse_off, h->sse_dev,
+                       h->replay ? h->loss_tab : nullptr, (const int*)h->iter_dev);
     L.done();
     HIPCHK(hipGetLastError());
   }
@@ -565,10 +583,10 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         Launch L(h, K_REDUCE, 0, (double)n_wg * n * 4.0);
         if (l > 0 && l < D - 1) {   // slab layout == flat gradient layout [W | b]
           const int n4 = n / 4;
-          hipLaunchKernelGGL(k_reduce_vec, dim3((n4 + 31) / 32), dim3(256), 0, h->stream, (const float*)h->slab,
+          hipLaunchKernelGGL(k_reduce_vec, dim3((n4 + 7) / 8), dim3(256), 0, h->stream, (const float*)h->slab,
                              n_wg, (long)n, n4, h->grads + h->off_w[l], (int)ra.accumulate, ra.scale);
         } else {
-          hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, h->stream, ra);
+          hipLaunchKernelGGL(k_reduce, dim3((n + 15) / 16), dim3(256), 0, h->stream, ra);
         }
         L.done();
         HIPCHK(hipGetLastError());
@@ -579,7 +597,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
   if (want_sse || train) {
     Launch L(h, K_SSE, 0, (double)sse_off * 4);
     hipLaunchKernelGGL(k_sse_reduce, dim3(1), dim3(256), 0, h->stream, (const float*)h->sse_part, (int)sse_off,
-                       h->sse_dev);
+                       h->sse_dev, h->replay ? h->loss_tab : nullptr, (const int*)h->iter_dev);
     L.done();
     HIPCHK(hipGetLastError());
   }
@@ -686,6 +704,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   ALLOC(h->l0tab, (size_t)WD * 16);
   ALLOC(h->gh, (size_t)cfg->height * 4); ALLOC(h->gw, (size_t)cfg->width * 4);
   ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->p_stride * 16);
+  if (h->wide) ALLOC(h->Abuf, (size_t)(D - 1) * h->p_stride * 16);
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
   { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4); }
   h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
@@ -705,9 +724,13 @@ int sf_destroy(sf_handle* h) {
   if (h->stream || true) hipStreamSynchronize(h->stream);
   for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab,
-                  h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part, h->biasw,
+                  h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part, h->biasw, h->Abuf,
                   h->sse_dev};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (h->gexec) hipGraphExecDestroy(h->gexec);
+  if (h->gstream) { hipStreamDestroy(h->gstream); hipEventDestroy(h->gev_in); hipEventDestroy(h->gev_out); }
+  void* gptrs[] = {h->step_tab, h->loss_tab, h->iter_dev};
+  for (void* p : gptrs) if (p) hipFree(p);
   delete h;
   return SF_OK;
 }
@@ -817,6 +840,8 @@ int sf_adam_step(sf_handle* h, float lr) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   h->step += 1;
   AdamArgs a;
+  memset(&a, 0, sizeof(a));
+  if (h->replay) { a.tab = h->step_tab; a.iter = h->iter_dev; }
   a.p = h->params; a.g = h->grads; a.m = h->m; a.v = h->v; a.mask = h->has_mask ? h->mask : nullptr;
   a.n = h->P;
   a.beta1 = h->cfg.beta1; a.beta2 = h->cfg.beta2; a.eps = h->cfg.eps;
@@ -832,8 +857,91 @@ int sf_adam_step(sf_handle* h, float lr) {
   return refresh_images(h);
 }
 
+
+// ---- graph replay -----------------------------------------------------------------------------------------
+// One training step (forward, backward, reductions, Adam, weight images) is captured ONCE into a hipGraph on an
+// engine-owned stream and replayed n times; the only per-step scalars (Adam's bias-corrected step size, computed
+// on the host in double exactly as sf_adam_step does) are read from a device table indexed by a device counter.
+static int graph_prepare(sf_engine* h, int n) {
+  if (!h->gstream) {
+    HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->gev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->gev_out, hipEventDisableTiming));
+    HIPCHK(hipMalloc((void**)&h->iter_dev, 16));
+  }
+  if (n > h->tab_cap) {
+    if (h->step_tab) hipFree(h->step_tab);
+    if (h->loss_tab) hipFree(h->loss_tab);
+    h->step_tab = nullptr; h->loss_tab = nullptr; h->tab_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->step_tab, (size_t)n * 8));
+    HIPCHK(hipMalloc((void**)&h->loss_tab, (size_t)n * 8));
+    h->tab_cap = n;
+    if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // the graph holds the old table pointers
+  }
+  return SF_OK;
+}
+
+static int step_replay(sf_engine* h, const float* lr, int n, float* loss_out) {
+  int rc = graph_prepare(h, n);
+  if (rc) return rc;
+  std::vector<float> tab((size_t)n * 2);
+  for (int i = 0; i < n; ++i) {
+    const double t = (double)(h->step + i + 1);
+    const double bc1 = 1.0 - pow((double)h->cfg.beta1, t), bc2 = 1.0 - pow((double)h->cfg.beta2, t);
+    tab[2 * i] = (float)((double)lr[i] / bc1);
+    tab[2 * i + 1] = (float)sqrt(bc2);
+  }
+  hipStream_t user = h->stream;
+  HIPCHK(hipEventRecord(h->gev_in, user));
+  HIPCHK(hipStreamWaitEvent(h->gstream, h->gev_in, 0));
+  h->stream = h->gstream;
+  struct Restore { sf_engine* h; hipStream_t s; ~Restore() { h->stream = s; h->replay = false; } } restore{h, user};
+  HIPCHK(hipMemcpyAsync(h->step_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, h->gstream));
+  HIPCHK(hipStreamSynchronize(h->gstream));            // `tab` is pageable host memory: keep it alive until copied
+  HIPCHK(hipMemsetAsync(h->iter_dev, 0, 4, h->gstream));
+  rc = refresh_images(h);                                // parameters edited since the last pass
+  if (rc) return rc;
+  if (!h->gexec || h->g_img != h->img || h->g_mask != h->has_mask) {
+    if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed));
+    h->replay = true;
+    const int64_t step0 = h->step;
+    rc = run_pass(h, true, nullptr, true);
+    if (!rc) rc = sf_adam_step(h, 0.f);
+    if (!rc) hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, h->gstream, h->iter_dev);
+    h->step = step0;
+    h->replay = false;
+    const hipError_t e = hipStreamEndCapture(h->gstream, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(SF_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    const hipError_t e2 = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e2 != hipSuccess) { h->gexec = nullptr; return fail(SF_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+    h->g_img = h->img; h->g_mask = h->has_mask;
+  }
+  for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(h->gexec, h->gstream));
+  h->step += n;
+  h->images_dirty = false;
+  if (loss_out) {
+    std::vector<double> sse((size_t)n);
+    HIPCHK(hipMemcpyAsync(sse.data(), h->loss_tab, (size_t)n * 8, hipMemcpyDeviceToHost, h->gstream));
+    HIPCHK(hipStreamSynchronize(h->gstream));
+    for (int i = 0; i < n; ++i) loss_out[i] = (float)(sse[i] / (3.0 * (double)h->npix));
+  }
+  HIPCHK(hipEventRecord(h->gev_out, h->gstream));
+  HIPCHK(hipStreamWaitEvent(user, h->gev_out, 0));
+  return SF_OK;
+}
+
 int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) {
   if (!h || !lr || n_steps < 0) return fail(SF_ERR_INVALID, "bad argument");
+  if (!h->have_coords) return fail(SF_ERR_STATE, "sf_set_coords has not been called");
+  if (!h->img) return fail(SF_ERR_STATE, "sf_set_target has not been called");
+  // replay pays off where launch latency dominates: several steps of a single-chunk fit, profiling off
+  static const bool no_graph = getenv("SIREN_FIT_NO_GRAPH") != nullptr;
+  if (n_steps >= 4 && !h->prof && !no_graph && h->npix <= h->chunk_px && h->npix <= (1L << 21))
+    return step_replay(h, lr, n_steps, loss_out);
   for (int i = 0; i < n_steps; ++i) {
     int rc = run_pass(h, true, nullptr, true);
     if (rc) return rc;

@@ -65,6 +65,10 @@ struct OpF16 {
   }
   static DEV float lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
   static DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef SF_EXPERIMENT_NO_MFMA
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
                                                   0);
   }
@@ -72,6 +76,10 @@ struct OpF16 {
 
 // streaming store of one 16-byte piece element (scratch tensors are written once and read once much later)
 DEV void store_stream(u32x4* p, u32x4 v) {
+#ifdef SF_EXPERIMENT_NO_STORE   // timing-only build
+  asm volatile("" ::"v"(v));
+  return;
+#endif
 #ifdef SF_EXPERIMENT_NT_STORE
   __builtin_nontemporal_store(v, p);
 #else
@@ -235,7 +243,11 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
     }
     const u32x4* wt = sW + IM::tile_piece(nt) * 64 + lane;
 #pragma unroll
+#ifdef SF_EXPERIMENT_FWD_LDS1   // timing-only build: one LDS fragment read per tile instead of KS
+    for (int s = 0; s < KS; ++s) acc = OP::mfma(wt[0], B[s], acc);
+#else
     for (int s = 0; s < KS; ++s) acc = OP::mfma(wt[s * 64], B[s], acc);
+#endif
     return acc;
   };
   auto tile_epi = [&](const f32x16& acc, int nt, int l, u32x4* Bn) {
@@ -724,53 +736,68 @@ struct ReduceArgs {
   float scale;                      // 1 / gradient pre-scale (power of two; fp16 backward operands)
 };
 
-__global__ void k_reduce(ReduceArgs a) {
+// 256 threads = 16 outputs x 16 slab groups: group g sums slabs g, g+16, ... (independent loads, issued ahead),
+// then the 16 partial sums are combined in fixed order 0..15 => deterministic, and the serial chain per output
+// is n_wg/16 loads instead of n_wg (these launches are pure latency on small fits).
+__global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
+  __shared__ float sh[16][17];
   const long slab_sz = (long)a.slab_rows * a.slab_cols + a.slab_rows;
   const int nW = a.rows_out * a.cols_out;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nW + a.rows_out) return;
-  if (idx < nW) {
-    const int j = idx / a.cols_out, i = idx % a.cols_out;
-    float s = 0.f;
-    if (a.mode == 0) {
-      const float* p = a.slab + (long)j * a.slab_cols + i;
-      for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz];
+  const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + o;
+  const bool live = idx < nW + a.rows_out;
+  float s = 0.f;
+  if (live) {
+    if (idx < nW) {
+      const int j = idx / a.cols_out, i = idx % a.cols_out;
+      if (a.mode == 0) {
+        const float* p = a.slab + (long)j * a.slab_cols + i;
+#pragma unroll 4
+        for (int w = grp; w < a.n_wg; w += 16) s += p[w * slab_sz];
+      } else {
+        const float* p = a.slab + (long)j * a.slab_cols + 2 * i;
+#pragma unroll 4
+        for (int w = grp; w < a.n_wg; w += 16) s += p[w * slab_sz] + p[w * slab_sz + 1];
+      }
     } else {
-      const float* p = a.slab + (long)j * a.slab_cols + 2 * i;
-      for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz] + p[w * slab_sz + 1];
+      const float* p = a.slab + (long)a.slab_rows * a.slab_cols + (idx - nW);
+#pragma unroll 4
+      for (int w = grp; w < a.n_wg; w += 16) s += p[w * slab_sz];
     }
-    s *= a.scale;
-    a.gW[idx] = a.accumulate ? a.gW[idx] + s : s;
-  } else {
-    const int j = idx - nW;
-    const float* p = a.slab + (long)a.slab_rows * a.slab_cols + j;
-    float s = 0.f;
-    for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz];
-    s *= a.scale;
-    a.gb[j] = a.accumulate ? a.gb[j] + s : s;
+  }
+  sh[grp][o] = s;
+  __syncthreads();
+  if (grp == 0 && live) {
+    float t = sh[0][o];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) t += sh[g][o];
+    t *= a.scale;
+    float* dst = idx < nW ? a.gW + idx : a.gb + (idx - nW);
+    *dst = a.accumulate ? *dst + t : t;
   }
 }
 
 // Vectorised form for hidden layers, whose slab layout [W rows*cols | b rows] IS the flat-gradient
-// layout: out[i] = sum_w slab[w][i].  256 threads = 32 float4 columns x 8 slab groups; group g sums
-// slabs g, g+8, ... in order, groups are combined 0..7 in order (fixed order => deterministic).
+// layout: out[i] = sum_w slab[w][i].  256 threads = 8 float4 columns x 32 slab groups; group g sums
+// slabs g, g+32, ... in order, groups are combined 0..31 in order (fixed order => deterministic).
 __global__ __launch_bounds__(256) void k_reduce_vec(const float* slab, int n_wg, long stride, int n4, float* out,
                                                     int accumulate, float scale) {
-  __shared__ f32x4 sh[8][32];
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int i4 = blockIdx.x * 32 + col;
+  __shared__ f32x4 sh[32][8];
+  const int col = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int i4 = blockIdx.x * 8 + col;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i4 < n4) {
     const f32x4* p = reinterpret_cast<const f32x4*>(slab) + i4;
     const long st4 = stride / 4;
-    for (int w = grp; w < n_wg; w += 8) s += p[w * st4];
+#pragma unroll 4
+    for (int w = grp; w < n_wg; w += 32) s += p[w * st4];
   }
   sh[grp][col] = s;
   __syncthreads();
   if (grp == 0 && i4 < n4) {
     f32x4 t = sh[0][col];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) t += sh[g][col];
+    for (int g = 1; g < 32; ++g) t += sh[g][col];
     t *= scale;
     f32x4* o = reinterpret_cast<f32x4*>(out) + i4;
     *o = accumulate ? *o + t : t;
@@ -778,7 +805,8 @@ __global__ __launch_bounds__(256) void k_reduce_vec(const float* slab, int n_wg,
 }
 
 // sum of the per-workgroup SSE partials in double, fixed order
-__global__ void k_sse_reduce(const float* part, int n, double* out) {
+// (loss_tab / iter: graph replay mode of sf_step — the per-step value also goes to loss_tab[*iter])
+__global__ void k_sse_reduce(const float* part, int n, double* out, double* loss_tab, const int* iter) {
   __shared__ double sh[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
@@ -788,8 +816,14 @@ __global__ void k_sse_reduce(const float* part, int n, double* out) {
     if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out = sh[0];
+  if (threadIdx.x == 0) {
+    *out = sh[0];
+    if (loss_tab) loss_tab[*iter] = sh[0];
+  }
 }
+
+// graph replay mode: advances the device-side step index once per replayed step (last node of the graph)
+__global__ void k_tick(int* iter) { *iter += 1; }
 
 // ---------------------------------------------------------------------------------------------
 // k_adam: torch.optim.Adam single-tensor op order (torch 2.x): lerp for exp_avg, mul/addcmul for
@@ -799,10 +833,17 @@ struct AdamArgs {
   float* p; const float* g; float* m; float* v; const float* mask;
   long n;
   float beta1, beta2, eps, step_size, bc2_sqrt;
+  const float* tab;   // graph replay mode: {step_size, bc2_sqrt} of step *iter (precomputed on the host in double)
+  const int* iter;
 };
 __global__ void k_adam(AdamArgs a) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
+  if (a.tab) {
+    const int it = *a.iter;
+    a.step_size = a.tab[2 * it];
+    a.bc2_sqrt = a.tab[2 * it + 1];
+  }
   const float g = a.g[i];
   float m = a.m[i], v = a.v[i];
   m = m + (1.0f - a.beta1) * (g - m);

@@ -3,12 +3,16 @@
 // The fused kernels of siren_kernels.hip keep a whole activation vector per pixel in registers and a
 // whole 256x256 weight gradient per workgroup; neither fits beyond width 256.  Wide networks therefore run
 // layer by layer with the activations (phases) and deltas in HBM, still in F-layout, through three kernels:
-//   k_wlayer0   phases of layer 0 from the coordinates (elementwise)
-//   k_wgemm     Out^T[256-neuron block x 32 pixels per wave] = A-block * B, A (weights) streamed through an
-//               LDS ring by LDS-DMA, B (input pieces) read from HBM/L2.  MODE 0: forward hidden layer
-//               (B = sin(phase), epilogue -> phase), MODE 1: forward last layer + residual/loss,
-//               MODE 2: backward data (B = delta, epilogue x cos(phase) -> delta)
-//   k_wdw       weight gradient of one 256x256 (or 32x256) block: delta^T * sin(phase), the W phase of k_bwd
+//   k_wlayer0   phases and activations of layer 0 from the coordinates (elementwise)
+//   k_wgemm     Out^T[256-neuron block x 256 pixels per workgroup] = A-block * B, A (weights) streamed through
+//               an LDS ring by LDS-DMA, B (input pieces) read from HBM/L2 into registers two chunks ahead.
+//               MODE 0: forward hidden layer (B = activation, epilogue -> phase AND activation),
+//               MODE 1: forward last layer + residual/loss, MODE 2: backward data (B = delta, epilogue x cos(phase))
+//   k_wdw       weight gradient blocks: delta^T * activation, both operands read transposed from an LDS ring
+// Unlike the fused width-256 path, each hidden layer keeps BOTH its phase (unorm16, for cos in the backward)
+// and its activation sin(phase) (16-bit float, the GEMM operand) in HBM: every value is an operand of WD/256
+// workgroups per product, so decoding phases inside the GEMM loops would repeat the transcendental WD/256 times
+// and put as many VALU cycles as MFMA cycles into the inner loop.
 // Arithmetic intensity grows with the width (FLOPs ~ W^2, bytes ~ W), so this path is less HBM-starved than
 // the width-256 one even without fusion.  Reference arithmetic: same lines as siren_kernels.hip.
 #pragma once
@@ -74,8 +78,9 @@ __global__ void k_wtables(WTabArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 struct WL0Args {
   const float* gh; const float* gw; int W, row_begin; long pix0, npix;
-  const f32x4* l0tab; float sc_first; int KS; long n_pieces; u32x4* P;
+  const f32x4* l0tab; float sc_first; int KS; long n_pieces; u32x4* P; u32x4* Act;
 };
+template <typename OP2>
 __global__ __launch_bounds__(256) void k_wlayer0(WL0Args a) {
   const long piece = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (piece >= a.n_pieces) return;
@@ -86,14 +91,18 @@ __global__ __launch_bounds__(256) void k_wlayer0(WL0Args a) {
   if (pix >= a.npix) pix = a.npix - 1;
   const int row = (int)(pix / a.W), col = (int)(pix - (long)row * a.W);
   const float x0 = (a.gh[a.row_begin + row] - 0.5f) * 2.0f, x1 = (a.gw[col] - 0.5f) * 2.0f;
-  float ph[8];
+  float ph[8], av[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const f32x4 t = a.l0tab[16 * s + pi_perm(h, j)];
-    ph[j] = __builtin_amdgcn_fractf(__builtin_fmaf(t.y, x1, __builtin_fmaf(t.x, x0, t.z)) * a.sc_first);
+    const float tt = __builtin_fmaf(t.y, x1, __builtin_fmaf(t.x, x0, t.z)) * a.sc_first;
+    ph[j] = __builtin_amdgcn_fractf(tt);
+    av[j] = __builtin_amdgcn_sinf(tt);
   }
   a.P[piece * 64 + lane] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
                                  pack_phase2(ph[6], ph[7])};
+  a.Act[piece * 64 + lane] =
+      u32x4{OP2::pack2(av[0], av[1]), OP2::pack2(av[2], av[3]), OP2::pack2(av[4], av[5]), OP2::pack2(av[6], av[7])};
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -103,137 +112,163 @@ struct WGemmArgs {
   const u32x4* A;        // blocked image of this layer: block ob at A + ob * a_block_pieces * 64
   long a_block_pieces;   // pieces per output block = n_chunk * OT * 4
   int n_chunk;           // K chunks of 4 k-steps
-  const u32x4* Bin;      // input tensor (F-layout, ks_in k-steps per pixel block): phases (MODE 0/1) or deltas (MODE 2)
+  const u32x4* Bin;      // input tensor (F-layout, ks_in k-steps per pixel block): activations (MODE 0/1) or deltas (MODE 2)
   int ks_in;
   const float* bias;     // MODE 0/1: [out rows], pre-scaled; nullptr otherwise
   float sc;              // MODE 0: omega/(2 pi)/wscale ; MODE 1: 1/wscale ; MODE 2: unused
   u32x4* Out;            // MODE 0: phases out, MODE 2: deltas out (F-layout, ks_out k-steps per block)
+  u32x4* OutAct;         // MODE 0: activations out (same geometry as Out)
   int ks_out;
   const u32x4* Pprev;    // MODE 2: phases of the layer whose delta is produced (same geometry as Out)
   // MODE 1 (last layer)
   const float* img; float* pred; float gscale; float* sse_part; u32x4* Dlast; long pix0, npix;
+  int n_super, n_ob;     // 256-pixel super-blocks of the chunk, output blocks; grid = roundup(n_super, 8) * n_ob
 };
 
+// Workgroup = 8 waves = 256 pixels x one block of 256 output neurons (MODE 1: the 32 padded rows of the last
+// layer).  MODE 0/2: wave w owns the 64 pixels of pixel-block pair w>>1 and the 128 outputs of half w&1, so
+// every A fragment read from LDS feeds TWO MFMAs (LDS bytes per MFMA halved against one 32-pixel block per
+// wave; the 128 accumulator registers are the budget of an 8-wave workgroup).
 template <int MODE, typename OP>
 __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
-  constexpr int OT = MODE == 1 ? 1 : 8;
+  constexpr int OT = MODE == 1 ? 1 : 8;       // 32-row tiles per LDS chunk
+  constexpr int TW = MODE == 1 ? 1 : 4;       // tiles per wave
+  constexpr int PBW = MODE == 1 ? 1 : 2;      // pixel blocks per wave
   constexpr int NB = 4, CH = OT * 4 * 1024;   // ring slots, bytes per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sRed = reinterpret_cast<float*>(smem + NB * CH);
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ob = blockIdx.y;
-  const long pb = (long)blockIdx.x * kWavesFwd + wave;
+  // XCD-aware 1-D grid: consecutive workgroup ids go to consecutive XCDs (8), each with its own L2.  The n_ob
+  // workgroups that read the SAME 256 pixels (one per output block) are made consecutive on ONE XCD, so the
+  // input pieces come from HBM once and from that XCD's L2 for the siblings.
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int ob = q % a.n_ob;
+  const int sb = (q / a.n_ob) * 8 + xcd;                                // 256-pixel super-block
+  if (sb >= a.n_super) return;                                          // grid padding (whole workgroup leaves)
+  const int t0 = MODE == 1 ? 0 : TW * (wave & 1);                       // first tile of this wave inside the block
+  const long pb0 = (long)sb * kWavesFwd + (MODE == 1 ? wave : 2 * (wave >> 1));
   const u32x4* Ablk = a.A + (size_t)ob * a.a_block_pieces * 64;
   auto stage = [&](int c) {
     char* base = smem + (c % NB) * CH;
     for (int pc = wave; pc < OT * 4; pc += kWavesFwd) glds16(Ablk + ((size_t)c * OT * 4 + pc) * 64 + lane, base + pc * 1024);
   };
-  f32x16 acc[OT];
+  f32x16 acc[TW][PBW];
 #pragma unroll
-  for (int ot = 0; ot < OT; ++ot) {
+  for (int t = 0; t < TW; ++t) {
+    f32x16 init = f32x16{};
     if (MODE != 2) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&a.bias[(ob * OT + ot) * 32 + 8 * q4 + 4 * h]);
-        acc[ot][4 * q4 + 0] = b.x; acc[ot][4 * q4 + 1] = b.y; acc[ot][4 * q4 + 2] = b.z; acc[ot][4 * q4 + 3] = b.w;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&a.bias[(ob * OT + t0 + t) * 32 + 8 * q4 + 4 * h]);
+        init[4 * q4 + 0] = b.x; init[4 * q4 + 1] = b.y; init[4 * q4 + 2] = b.z; init[4 * q4 + 3] = b.w;
       }
-    } else {
-      acc[ot] = f32x16{};
     }
+#pragma unroll
+    for (int p = 0; p < PBW; ++p) acc[t][p] = init;
   }
   float tgt[3] = {0.f, 0.f, 0.f};
-  const long pix = a.pix0 + pb * 32 + m;
+  const long pix = a.pix0 + pb0 * 32 + m;
   const bool valid = MODE == 1 && pix < a.npix;
   if (MODE == 1 && a.img && h == 0 && valid) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) tgt[c] = a.img[pix * 3 + c];
   }
-  asm volatile("" ::"v"(tgt[0]), "v"(tgt[1]), "v"(tgt[2]), "v"(acc[0][0]));
-  // B pieces (raw phases / deltas) are prefetched TWO chunks ahead into registers, right behind the LDS-DMA of
-  // the same chunk: vmcnt counts both in issue order, so "everything but the youngest G + 4 operations" at the
-  // top of a step means chunk c (A in LDS, B in registers) has landed while chunk c+1 stays in flight.
+  asm volatile("" ::"v"(tgt[0]), "v"(tgt[1]), "v"(tgt[2]), "v"(acc[0][0][0]));
+  // B pieces are prefetched TWO chunks ahead into registers, right behind the LDS-DMA of the same chunk: vmcnt
+  // counts both in issue order, so "everything but the youngest G + 4*PBW operations" at the top of a step means
+  // chunk c (A in LDS, B in registers) has landed while chunk c+1 stays in flight.
   constexpr int G = OT * 4 / kWavesFwd;      // LDS-DMA instructions per wave per chunk (0: uneven -> full waits)
-  auto load_b = [&](int c, u32x4 (&raw)[4]) {
+  auto load_b = [&](int c, u32x4 (&raw)[PBW][4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int sidx = 4 * c + i;
-      sidx = sidx < a.ks_in ? sidx : a.ks_in - 1;
-      raw[i] = a.Bin[(pb * a.ks_in + sidx) * 64 + lane];
-    }
+    for (int p = 0; p < PBW; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int sidx = 4 * c + i;
+        sidx = sidx < a.ks_in ? sidx : a.ks_in - 1;
+        raw[p][i] = a.Bin[((pb0 + p) * a.ks_in + sidx) * 64 + lane];
+      }
   };
-  u32x4 r0[4], r1[4], r2[4];
+  u32x4 r0[PBW][4], r1[PBW][4], r2[PBW][4];
   stage(0);
   load_b(0, r0);
   if (a.n_chunk > 1) { stage(1); load_b(1, r1); }
   for (int c = 0; c < a.n_chunk; ++c) {
-    if (G > 0 && c + 1 < a.n_chunk) bar_dma<G + 4>(); else bar_all();
+    if (G > 0 && c + 1 < a.n_chunk) bar_dma<G + 4 * PBW>(); else bar_all();
     if (c + 2 < a.n_chunk) { stage(c + 2); load_b(c + 2, r2); }
     asm volatile("" ::: "memory");
-    u32x4 b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      u32x4 v = r0[i];
-      if (MODE != 2) {   // phases -> activations
-        u32x4 o;
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2)
-          o[j2] = OP::pack2(__builtin_amdgcn_sinf(phase_rev_lo(v[j2])), __builtin_amdgcn_sinf(phase_rev_hi(v[j2])));
-        v = o;
-      }
-      b[i] = 4 * c + i < a.ks_in ? v : u32x4{0u, 0u, 0u, 0u};
-    }
     const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * CH) + lane;
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    for (int i = 0; i < 4; ++i) {
+      u32x4 b[PBW];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[ot] = OP::mfma(sA[(ot * 4 + i) * 64], b[i], acc[ot]);
+      for (int p = 0; p < PBW; ++p) b[p] = 4 * c + i < a.ks_in ? r0[p][i] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { r0[i] = r1[i]; r1[i] = r2[i]; }
+      for (int t = 0; t < TW; ++t) {
+        const u32x4 fa = sA[((t0 + t) * 4 + i) * 64];
+#pragma unroll
+        for (int p = 0; p < PBW; ++p) acc[t][p] = OP::mfma(fa, b[p], acc[t][p]);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PBW; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { r0[p][i] = r1[p][i]; r1[p][i] = r2[p][i]; }
   }
   // ---- epilogues ----
   if (MODE == 0) {
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    for (int t = 0; t < TW; ++t)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float ph[8];
+      for (int p = 0; p < PBW; ++p)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ph[j] = __builtin_amdgcn_fractf(acc[ot][8 * q + j] * a.sc);
-        a.Out[(pb * a.ks_out + 16 * ob + 2 * ot + q) * 64 + lane] =
-            u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]), pack_phase2(ph[6], ph[7])};
-      }
+        for (int q = 0; q < 2; ++q) {
+          float ph[8], av[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float tt = acc[t][p][8 * q + j] * a.sc;
+            ph[j] = __builtin_amdgcn_fractf(tt);
+            av[j] = __builtin_amdgcn_sinf(tt);
+          }
+          const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + q) * 64 + lane;
+          a.Out[pidx] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
+                              pack_phase2(ph[6], ph[7])};
+          a.OutAct[pidx] = u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]),
+                                 OP::pack2(av[6], av[7])};
+        }
   } else if (MODE == 2) {
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    for (int t = 0; t < TW; ++t)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const long pidx = (pb * a.ks_out + 16 * ob + 2 * ot + q) * 64 + lane;
-        const u32x4 p = a.Pprev[pidx];
-        u32x4 o;
+      for (int p = 0; p < PBW; ++p)
 #pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2)
-          o[j2] = OP::pack2(acc[ot][8 * q + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(p[j2])),
-                            acc[ot][8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(p[j2])));
-        a.Out[pidx] = o;
-      }
+        for (int q = 0; q < 2; ++q) {
+          const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + q) * 64 + lane;
+          const u32x4 pv = a.Pprev[pidx];
+          u32x4 o;
+#pragma unroll
+          for (int j2 = 0; j2 < 4; ++j2)
+            o[j2] = OP::pack2(acc[t][p][8 * q + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(pv[j2])),
+                              acc[t][p][8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(pv[j2])));
+          a.Out[pidx] = o;
+        }
   } else {
     float sse = 0.f, d[3] = {0.f, 0.f, 0.f};
     if (h == 0 && valid) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float p = acc[0][c] * a.sc * 0.5f + 0.5f;
-        if (a.pred) a.pred[pix * 3 + c] = p;
+        const float pr = acc[0][0][c] * a.sc * 0.5f + 0.5f;
+        if (a.pred) a.pred[pix * 3 + c] = pr;
         if (a.img) {
-          const float r = p - tgt[c];
+          const float r = pr - tgt[c];
           sse += r * r;
           d[c] = r * a.gscale;
         }
       }
     }
     if (a.Dlast) {
-      a.Dlast[(pb * 2 + 0) * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
-      a.Dlast[(pb * 2 + 1) * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
+      a.Dlast[(pb0 * 2 + 0) * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
+      a.Dlast[(pb0 * 2 + 1) * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
@@ -242,19 +277,18 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
     if (tid == 0 && a.sse_part) {
       float t = 0.f;
       for (int w = 0; w < kWavesFwd; ++w) t += sRed[w];
-      a.sse_part[blockIdx.x] = t;
+      a.sse_part[sb] = t;
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_wdw: one [JW x 256] block of a weight gradient: dW[jb-block][ib-block] = delta[:, jb]^T * sin(phase[:, ib])
-//   ring of 32-pixel blocks as in k_bwd; the phase pieces are converted to activations in place by the waves
-//   (no X phase here), then both operands are read transposed.
+// k_wdw: [JW x 256] blocks of a weight gradient: dW[jb-block][ib-block] = delta[:, jb]^T * act[:, ib]
+//   ring of 32-pixel blocks as in k_bwd; both operands are read transposed (ds_read_b64_tr_b16).
 // ---------------------------------------------------------------------------------------------------------
 struct WDwArgs {
   const u32x4* D; int ksd_total;            // delta tensor of layer l: k-steps per pixel block
-  const u32x4* P; int ksp_total;            // phase tensor of layer l-1
+  const u32x4* P; int ksp_total;            // activation tensor of layer l-1
   int nblk_i;                               // 256-column blocks of the phase tensor: blockIdx.y = jb * nblk_i + ib
   long n_pb;
   float* slab;                              // [gridDim.y][gridDim.x][JW*256 + JW]
@@ -299,16 +333,6 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
     asm volatile("" ::: "memory");
     char* sD = smem + (k % NB) * BLK;
     char* sP = sD + KSJ * 1024;
-    for (int pc = wave; pc < KSI; pc += NW) {      // phases -> activations, in place
-      u32x4* pp = reinterpret_cast<u32x4*>(sP + pc * 1024) + lane;
-      const u32x4 p = *pp;
-      u32x4 o;
-#pragma unroll
-      for (int j2 = 0; j2 < 4; ++j2)
-        o[j2] = OP::pack2(__builtin_amdgcn_sinf(phase_rev_lo(p[j2])), __builtin_amdgcn_sinf(phase_rev_hi(p[j2])));
-      *pp = o;
-    }
-    bar_lds();
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       u32x4 fa[WJ], fb[WI];

@@ -445,3 +445,29 @@ def test_wide_host_mirror_padded_width():
     m.download_params()
     for a, b in zip(m._param_list(), p):
         assert (a.detach().cpu() - b).abs().max() <= 6.2e-4   # one Adam step moves <= lr; sign flips on ~0 gradients
+
+
+def test_graph_replay_equals_eager_steps():
+    """sf_step replays a captured hipGraph for n >= 4 steps of a single-chunk fit; one-step calls run eagerly.
+    Same kernels in the same order => parameters, Adam state and losses are bit-identical."""
+    H, W, hidden, depth = 40, 56, 64, 4
+    p = so.siren_init(hidden, depth, seed=1)
+    img = so.synthetic_image(H, W, seed=4)
+    lrs = [3e-4 * (0.5 ** (t // 5)) for t in range(13)]
+    a = _engine(H, W, hidden, depth, "f16", p, img)
+    b = _engine(H, W, hidden, depth, "f16", p, img)
+    la = a.step(lrs, want_loss=True)                       # replay
+    la += a.step(lrs[:6], want_loss=True)                  # cached graph, fewer steps
+    lb = [b.step([lr], want_loss=True)[0] for lr in lrs + lrs[:6]]
+    assert la == lb
+    assert torch.equal(a.get_params(), b.get_params())
+    ma, va, sa = a.get_adam_state()
+    mb, vb, sb = b.get_adam_state()
+    assert sa == sb == 19 and torch.equal(ma, mb) and torch.equal(va, vb)
+    mask = (torch.rand(a.num_params, device="cuda") > 0.5).float()
+    a.set_masks(mask); b.set_masks(mask)                    # mask toggles -> the graph is re-captured
+    a.step(lrs[:4]); [b.step([lr]) for lr in lrs[:4]]
+    assert torch.equal(a.get_params(), b.get_params())
+    pa, _ = a.forward()
+    pb, _ = b.forward()
+    assert torch.equal(pa, pb)
