@@ -82,6 +82,8 @@ struct sf_engine {
   const float* g_img = nullptr;
   bool g_mask = false;
   bool replay = false;      // launches issued now belong to a replayed step: per-step scalars come from device tables
+  bool want_replay = false; // sf_set_graph_replay
+  double* loss_dst = nullptr;   // eager multi-step sf_step: where k_sse_reduce also stores this step's SSE
   float* step_tab = nullptr;
   double* loss_tab = nullptr;
   int* iter_dev = nullptr;
@@ -477,7 +479,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
   if (want_sse || train) {
     Launch L(h, K_SSE, 0, (double)sse_off * 4);
     hipLaunchKernelGGL(k_sse_reduce, dim3(1), dim3(256), 0, h->stream, (const float*)h->sse_part, (int)sse_off, h->sse_dev,
-                       h->replay ? h->loss_tab : nullptr, (const int*)h->iter_dev);
+                       h->replay ? h->loss_tab : h->loss_dst, (const int*)(h->replay ? h->iter_dev : h->iter_dev + 2));
     L.done();
     HIPCHK(hipGetLastError());
   }
@@ -597,7 +599,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
   if (want_sse || train) {
     Launch L(h, K_SSE, 0, (double)sse_off * 4);
     hipLaunchKernelGGL(k_sse_reduce, dim3(1), dim3(256), 0, h->stream, (const float*)h->sse_part, (int)sse_off,
-                       h->sse_dev, h->replay ? h->loss_tab : nullptr, (const int*)h->iter_dev);
+                       h->sse_dev, h->replay ? h->loss_tab : h->loss_dst, (const int*)(h->replay ? h->iter_dev : h->iter_dev + 2));
     L.done();
     HIPCHK(hipGetLastError());
   }
@@ -868,6 +870,7 @@ static int graph_prepare(sf_engine* h, int n) {
     HIPCHK(hipEventCreateWithFlags(&h->gev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->gev_out, hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&h->iter_dev, 16));
+    HIPCHK(hipMemset(h->iter_dev, 0, 16));   // [0] replay step index, [2] constant 0 (eager table index)
   }
   if (n > h->tab_cap) {
     if (h->step_tab) hipFree(h->step_tab);
@@ -938,10 +941,24 @@ int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) {
   if (!h || !lr || n_steps < 0) return fail(SF_ERR_INVALID, "bad argument");
   if (!h->have_coords) return fail(SF_ERR_STATE, "sf_set_coords has not been called");
   if (!h->img) return fail(SF_ERR_STATE, "sf_set_target has not been called");
-  // replay pays off where launch latency dominates: several steps of a single-chunk fit, profiling off
-  static const bool no_graph = getenv("SIREN_FIT_NO_GRAPH") != nullptr;
-  if (n_steps >= 4 && !h->prof && !no_graph && h->npix <= h->chunk_px && h->npix <= (1L << 21))
-    return step_replay(h, lr, n_steps, loss_out);
+  if (h->want_replay && n_steps >= 2 && !h->prof && h->npix <= h->chunk_px) return step_replay(h, lr, n_steps, loss_out);
+  if (loss_out && n_steps > 1) {
+    // eager, but without a host sync per step: every step's SSE goes to a device table, read back once
+    int rc = graph_prepare(h, n_steps);
+    if (rc) return rc;
+    for (int i = 0; i < n_steps && !rc; ++i) {
+      h->loss_dst = h->loss_tab + i;
+      rc = run_pass(h, true, nullptr, true);
+      h->loss_dst = nullptr;
+      if (!rc) rc = sf_adam_step(h, lr[i]);
+    }
+    if (rc) return rc;
+    std::vector<double> sse((size_t)n_steps);
+    HIPCHK(hipMemcpyAsync(sse.data(), h->loss_tab, (size_t)n_steps * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n_steps; ++i) loss_out[i] = (float)(sse[i] / (3.0 * (double)h->npix));
+    return SF_OK;
+  }
   for (int i = 0; i < n_steps; ++i) {
     int rc = run_pass(h, true, nullptr, true);
     if (rc) return rc;
@@ -954,6 +971,12 @@ int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) {
     rc = sf_adam_step(h, lr[i]);
     if (rc) return rc;
   }
+  return SF_OK;
+}
+
+int sf_set_graph_replay(sf_handle* h, int32_t on) {
+  if (!h) return fail(SF_ERR_INVALID, "null argument");
+  h->want_replay = on != 0;
   return SF_OK;
 }
 

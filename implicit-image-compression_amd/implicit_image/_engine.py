@@ -60,7 +60,7 @@ def load_library():
         "sf_forward_backward": [H, C.POINTER(C.c_double)],
         "sf_adam_step": [H, C.c_float],
         "sf_step": [H, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)],
-        "sf_profile_enable": [H, C.c_int32], "sf_profile_reset": [H],
+        "sf_profile_enable": [H, C.c_int32], "sf_profile_reset": [H], "sf_set_graph_replay": [H, C.c_int32],
         "sf_profile_num_kernels": [H, C.POINTER(C.c_int32)],
         "sf_profile_get": [H, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(I64),
                            C.POINTER(C.c_double), C.POINTER(C.c_double)],
@@ -225,6 +225,10 @@ class SirenEngine:
         out = (C.c_float * n)() if want_loss else None
         _check(self.lib.sf_step(self.h, arr, n, out))
         return list(out) if want_loss else None
+
+    def set_graph_replay(self, on: bool):
+        """step(): replay a captured hipGraph per training step instead of launching kernel by kernel"""
+        _check(self.lib.sf_set_graph_replay(self.h, int(on)))
 
     # ---- measurement -----------------------------------------------------------------------
     def profile(self, on: bool):

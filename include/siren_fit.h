@@ -115,6 +115,11 @@ int sf_adam_step(sf_handle* h, float lr);
 /* n_steps x (forward_backward + adam_step) with learning rates lr[0..n_steps) (host array);
  * loss_out (host, may be NULL) receives the MSE of every step (length n_steps) */
 int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out);
+/* sf_step execution mode for single-chunk fits: 0 (default) = one stream launch per kernel, 1 = capture one
+ * training step into a hipGraph and replay it n_steps times.  Results are bit-identical; which is faster is a
+ * property of the runtime (measured on ROCm 7.2 / MI355X: eager 73 us/step vs replay 87 us/step at SIREN 64x4
+ * on 256x256), so replay stays opt-in. */
+int sf_set_graph_replay(sf_handle* h, int32_t on);
 
 /* measurement: per-kernel HIP-event timing on the handle's stream */
 int sf_profile_enable(sf_handle* h, int32_t on);

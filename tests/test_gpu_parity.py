@@ -448,7 +448,8 @@ def test_wide_host_mirror_padded_width():
 
 
 def test_graph_replay_equals_eager_steps():
-    """sf_step replays a captured hipGraph for n >= 4 steps of a single-chunk fit; one-step calls run eagerly.
+    """sf_set_graph_replay(1): sf_step replays a captured hipGraph per step; one-step calls run eagerly, and so
+    do multi-step calls on a default handle (per-step losses through a device table, one read-back).
     Same kernels in the same order => parameters, Adam state and losses are bit-identical."""
     H, W, hidden, depth = 40, 56, 64, 4
     p = so.siren_init(hidden, depth, seed=1)
@@ -456,6 +457,12 @@ def test_graph_replay_equals_eager_steps():
     lrs = [3e-4 * (0.5 ** (t // 5)) for t in range(13)]
     a = _engine(H, W, hidden, depth, "f16", p, img)
     b = _engine(H, W, hidden, depth, "f16", p, img)
+    c = _engine(H, W, hidden, depth, "f16", p, img)
+    a.set_graph_replay(True)
+    assert c.step(lrs + lrs[:6], want_loss=True) == [b.step([lr], want_loss=True)[0] for lr in lrs + lrs[:6]]
+    assert torch.equal(c.get_params(), b.get_params())
+    b.set_params(torch.tensor(so.flatten(p)).cuda())
+    b.set_adam_state(torch.zeros(b.num_params, device="cuda"), torch.zeros(b.num_params, device="cuda"), 0)
     la = a.step(lrs, want_loss=True)                       # replay
     la += a.step(lrs[:6], want_loss=True)                  # cached graph, fewer steps
     lb = [b.step([lr], want_loss=True)[0] for lr in lrs + lrs[:6]]
