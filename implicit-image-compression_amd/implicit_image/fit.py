@@ -23,7 +23,8 @@ from .models import registry as model_registry
 from .parallel import shard_jobs
 from .pipeline import entropy_coding
 from .pipeline.quant import Quantize
-from .utils.train_helper import eval_epoch, get_device, get_optimizer_lr_scheduler, setup_mask, train_epoch
+from .utils.train_helper import (eval_epoch, get_device, get_optimizer_lr_scheduler, setup_mask, train_epoch,
+                                 train_steps)
 
 REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 
@@ -49,8 +50,16 @@ def fit_one(cfg: Cfg, device: torch.device, out_dir: str = None):
             mcfg.interval = int(mcfg.interval * mult)
     mask = setup_mask(model, optim, mcfg)                                          # compress.py:127
     t0, last = time.time(), {}
-    for i in range(num_steps):                                                     # compress.py:137-170
-        train_epoch(model, optim, grid, img, lr_scheduler=lr_scheduler, mask=mask)
+    i = -1
+    while i + 1 < num_steps:                                                       # compress.py:137-170
+        # the iterations up to the next one that needs the host (topology update / logging) go to the engine
+        # in one call; train_steps() is bit-identical to calling train_epoch() once per iteration
+        first = i + 1
+        i = first
+        while not ((mask and i <= mcfg.end_when and i % mcfg.interval == 0)
+                   or (i + 1) % cfg.train.log_steps == 0 or i + 1 == num_steps):
+            i += 1
+        train_steps(model, optim, grid, img, i - first + 1, lr_scheduler=lr_scheduler, mask=mask)
         if mask and i <= mcfg.end_when and i % mcfg.interval == 0:
             mask.update_connections()
         if (i + 1) % cfg.train.log_steps == 0 or i + 1 == num_steps:

@@ -156,6 +156,47 @@ def train_epoch(model: Module, optim: Optimizer, grid, img, **kwargs) -> float:
     return loss
 
 
+def train_steps(model: Module, optim: Optimizer, grid, img, n: int, **kwargs):
+    """`n` consecutive train_epoch() calls, returned as the list of their losses.
+
+    The reference loop (compress.py:137-170) syncs with the device every iteration for `train_loss.item()`.
+    When nothing on the host has to look at the state between two steps (no per-layer callbacks, no padded
+    width, masks either absent or applied inside the engine's Adam kernel with dense gradients) the n steps go
+    to the engine in ONE call (`sf_step`): same kernels in the same order, so the result is bit-identical to
+    the step-by-step loop, but the stream never drains and the losses come back in one read."""
+    mask: Masking = kwargs.get("mask")
+    lr_scheduler = kwargs.get("lr_scheduler")
+    pbar = kwargs.get("pbar")
+    bulk = (n > 1 and isinstance(optim, EngineAdam) and not getattr(model, "_padded", False)
+            and not getattr(model, "post_backward_callbacks", None)
+            and kwargs.get("criterion", F.mse_loss) is F.mse_loss and kwargs.get("preconditioner") is None
+            and (mask is None or (mask.dense_gradients and mask.prune_rate_decay.mode != "cumulative"
+                                  and getattr(optim, "applies_engine_mask", False))))
+    if not bulk:
+        return [train_epoch(model, optim, grid, img, **kwargs) for _ in range(n)]
+    model.train()
+    eng = model.engine(grid, img)
+    optim._bind_state(eng)
+    if mask is not None and mask._pushed_engine is not eng:
+        mask._push_masks()
+    lrs = []
+    for _ in range(n):                       # the schedule is host-side bookkeeping: run it ahead
+        lrs.append(float(optim.param_groups[0]["lr"]))
+        if lr_scheduler:
+            optim._opt_called = True         # what the scheduler's wrapper around Optimizer.step() records
+            lr_scheduler.step()
+    losses = eng.step(lrs, want_loss=True)
+    for p in model._param_list():
+        optim.state[p]["step"] += n
+    if mask is not None:
+        for _ in range(n):                   # prune-rate decay + step counter of Masking.step (core.py:690-702)
+            mask.prune_rate_decay.step(mask.mask_step)
+            mask.mask_step += 1
+    if pbar:
+        pbar.update(n)
+    return losses
+
+
 @torch.no_grad()
 def eval_epoch(model: Module, grid, img, **kwargs) -> Tuple[torch.Tensor, float, float, float]:
     model.eval()

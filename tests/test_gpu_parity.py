@@ -478,3 +478,45 @@ def test_graph_replay_equals_eager_steps():
     pa, _ = a.forward()
     pb, _ = b.forward()
     assert torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_train_steps_bulk_equals_step_by_step(with_mask):
+    """train_steps(n) (one sf_step call between host events, used by fit_one) against n train_epoch() calls:
+    losses, weights, masks, prune-rate schedule and learning-rate schedule must be bit-identical."""
+    from implicit_image.data import get_grid
+    from implicit_image.models import registry
+    from implicit_image.utils.train_helper import get_optimizer_lr_scheduler, setup_mask, train_epoch, train_steps
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+    H, W = 48, 40
+    img, grid = so.synthetic_image(H, W, seed=9).cuda(), get_grid(H, W).cuda()
+    runs = []
+    for bulk in (False, True):
+        torch.manual_seed(0)
+        model = registry["siren"](depth=4, hidden_size=64, first_omega_0=50, hidden_omega_0=30).to("cuda")
+        optim, sched = get_optimizer_lr_scheduler(model, Cfg(name="adam", lr=3e-4))
+        sched.step_size = 7                                   # exercise the StepLR boundary inside a bulk call
+        mask = None
+        if with_mask:
+            mcfg = Cfg(name="RigL", density=0.5, sparse_init="erdos-renyi-kernel", dense_gradients=True,
+                       growth_mode="absolute-gradient", prune_mode="magnitude", redistribution_mode="none",
+                       dense=False, prune_rate=0.1, decay_schedule="cosine", end_when=30, interval=10)
+            mask = setup_mask(model, optim, mcfg)
+        losses = []
+        for first in range(0, 30, 10):
+            if bulk:
+                losses += train_steps(model, optim, grid, img, 10, lr_scheduler=sched, mask=mask)
+            else:
+                losses += [train_epoch(model, optim, grid, img, lr_scheduler=sched, mask=mask) for _ in range(10)]
+            if mask:
+                mask.update_connections()
+        runs.append((losses, [p.detach().clone() for p in model._param_list()], optim.param_groups[0]["lr"],
+                     mask.prune_rate if mask else None, mask.mask_step if mask else None,
+                     [mask.mask_dict[k].clone() for k in sorted(mask.mask_dict)] if mask else []))
+    (la, pa, lra, ra, sa, ma), (lb, pb, lrb, rb, sb, mb) = runs
+    assert [float(np.float32(x)) for x in la] == [float(np.float32(x)) for x in lb]
+    assert lra == lrb and ra == rb and sa == sb
+    for x, y in zip(pa + ma, pb + mb):
+        assert torch.equal(x, y)
