@@ -183,14 +183,14 @@ def main():
             traffic = None
         ach = d["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
         out = {
-            "metric": "Mpixel-iters/s (fwd+bwd+Adam) @ SIREN-256x8",
+            "metric": f"Mpixel-iters/s (fwd+bwd+Adam) @ SIREN-{args.hidden}x{args.depth}",
             "value": value, "unit": "Mpixel-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if split else "weak",
             "vs_baseline": None, "dtype": "f16 (fp16 MFMA operands fwd+bwd, f32 accumulate, f32 optimiser state)" if args.dtype == "f16" else "bf16",
             "data": "synthetic",
             "config": {"workload": f"siren_{args.hidden}x{args.depth}_fit_step_{H}x{W}x3_grid", "image": f"{H}x{W}x3",
                        "hidden": args.hidden, "depth": args.depth, "sharding": (f"pixel-split rows x{world} + RCCL grad all-reduce" if split else f"per-image x{world}"),
-                       "chunk_pixels": eng.npix if args.chunk == 0 and eng.npix < (1 << 22) else (args.chunk or 1 << 22)},
+                       "chunk_pixels": min(eng.npix, args.chunk or (1 << 22) // max(1, args.hidden // 256))},
             "step_mfma_frac": value / world * 1e6 * F / (PEAK_BF16_TFLOPS * 1e12),   # per GPU
             "psnr_after_run": psnr,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

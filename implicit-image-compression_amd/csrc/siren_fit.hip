@@ -383,6 +383,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       a.bias = h->biasw + (size_t)(D - 2) * WD; a.sc = 1.0f / h->wscale;
       a.img = h->img; a.pred = pred; a.gscale = (float)((double)h->gpre / (3.0 * h->n_total));
       a.sse_part = h->sse_part + sse_off; a.Dlast = train ? h->Dlast : nullptr; a.pix0 = pix0; a.npix = h->npix;
+      if (!h->cfg.outermost_linear) { a.last_om = h->cfg.hidden_omega_0; a.last_om_rev = (float)((double)h->cfg.hidden_omega_0 / two_pi); }
       sse_off += n_super;
       Launch L(h, K_FWD, 2.0 * h->cfg.out_features * WD * npx, npx * (WD * 2.0 + 12.0 + 64.0));
       rc = launch_wgemm<1>(h, a, n_super, 1);
@@ -512,6 +513,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     fa.sc_first = (float)((double)h->cfg.first_omega_0 / two_pi);
     fa.sc_hidden = (float)((double)h->cfg.hidden_omega_0 / two_pi / (double)h->wscale);
     fa.sc_last = 1.0f / h->wscale;
+    if (!h->cfg.outermost_linear) { fa.last_om = h->cfg.hidden_omega_0; fa.last_om_rev = (float)((double)h->cfg.hidden_omega_0 / two_pi); }
     fa.P = h->Pbuf; fa.p_stride = h->p_stride; fa.Dlast = h->Dlast;
     fa.img = h->img;
     fa.gscale = (float)((double)h->gpre / (3.0 * h->n_total));
@@ -630,7 +632,6 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
       cfg->hidden != 1024)
     return fail(SF_ERR_INVALID, "hidden must be 32, 64, 128, 256, 512 or 1024 in this build");
   if (cfg->hidden > 256 && cfg->depth < 3) return fail(SF_ERR_INVALID, "hidden > 256 needs depth >= 3");
-  if (!cfg->outermost_linear) return fail(SF_ERR_INVALID, "outermost_linear=False is not supported");
   if (cfg->compute_dtype != SF_BF16 && cfg->compute_dtype != SF_F16)
     return fail(SF_ERR_INVALID, "compute_dtype must be SF_BF16 or SF_F16");
   if (cfg->height < 1 || cfg->width < 1) return fail(SF_ERR_INVALID, "bad image size");

@@ -152,6 +152,8 @@ struct FwdArgs {
   float sc_first;          // first_omega_0 / (2 pi)
   float sc_hidden;         // hidden_omega_0 / (2 pi) / weight-image scale
   float sc_last;           // 1 / weight-image scale
+  float last_om, last_om_rev;  // outermost_linear=False (siren.py:110-117): the last layer is sin(omega z) too;
+                               // omega and omega/(2 pi), both 0 for the (default) linear last layer
   u32x4* P;                // phases, layer l at P + l*p_stride, F-layout
   long p_stride;           // pieces per layer in the scratch
   u32x4* Dlast;            // delta of the last layer, F-layout with 2 k-steps (32 padded neurons), bf16
@@ -320,12 +322,18 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   if (h == 0 && valid) {  // rows 0..2 of the tile live in registers 0..2 of the lower lane half
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float p = acc[c] * a.sc_last * 0.5f + 0.5f;  // siren.py:131
+      float o = acc[c] * a.sc_last, dfac = 1.0f;
+      if (a.last_om_rev != 0.f) {   // sine output layer: d sin(om z)/dz = om cos(om z)
+        const float tt = o * a.last_om_rev;
+        o = __builtin_amdgcn_sinf(tt);
+        dfac = a.last_om * __builtin_amdgcn_cosf(tt);
+      }
+      const float p = o * 0.5f + 0.5f;  // siren.py:131
       if (a.pred) a.pred[pix * 3 + c] = p;
       if (a.img) {
         const float r = p - tgt[c];
         sse += r * r;
-        d[c] = r * a.gscale;
+        d[c] = r * a.gscale * dfac;
       }
     }
   }

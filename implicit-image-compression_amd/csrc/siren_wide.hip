@@ -122,6 +122,7 @@ struct WGemmArgs {
   const u32x4* Pprev;    // MODE 2: phases of the layer whose delta is produced (same geometry as Out)
   // MODE 1 (last layer)
   const float* img; float* pred; float gscale; float* sse_part; u32x4* Dlast; long pix0, npix;
+  float last_om, last_om_rev;   // sine output layer (outermost_linear=False), 0 otherwise
   int n_super, n_ob;     // 256-pixel super-blocks of the chunk, output blocks; grid = roundup(n_super, 8) * n_ob
 };
 
@@ -257,12 +258,18 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
     if (h == 0 && valid) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float pr = acc[0][0][c] * a.sc * 0.5f + 0.5f;
+        float o = acc[0][0][c] * a.sc, dfac = 1.0f;
+        if (a.last_om_rev != 0.f) {
+          const float tt = o * a.last_om_rev;
+          o = __builtin_amdgcn_sinf(tt);
+          dfac = a.last_om * __builtin_amdgcn_cosf(tt);
+        }
+        const float pr = o * 0.5f + 0.5f;
         if (a.pred) a.pred[pix * 3 + c] = pr;
         if (a.img) {
           const float r = pr - tgt[c];
           sse += r * r;
-          d[c] = r * a.gscale;
+          d[c] = r * a.gscale * dfac;
         }
       }
     }

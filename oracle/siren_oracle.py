@@ -79,9 +79,10 @@ def unflatten(flat, hidden: int, depth: int) -> List[torch.Tensor]:
 # siren.py:56-68, 123-134  forward ; train_helper.py:147-161  mse + backward
 # --------------------------------------------------------------------------------------------
 def forward(params: Sequence[torch.Tensor], grid: torch.Tensor, first_omega_0: float = 50.0,
-            hidden_omega_0: float = 30.0, keep: bool = False):
-    """Siren.forward: flatten grid, x = (x-0.5)*2, Linear -> sin(omega*z) per layer (last layer linear,
-    outermost_linear=True), out/2 + 0.5, reshape [H, W, 3]."""
+            hidden_omega_0: float = 30.0, keep: bool = False, outermost_linear: bool = True):
+    """Siren.forward: flatten grid, x = (x-0.5)*2, Linear -> sin(omega*z) per layer (last layer linear when
+    outermost_linear=True, the reference's configuration; sine with omega_0 = hidden_omega_0 otherwise,
+    siren.py:110-117), out/2 + 0.5, reshape [H, W, 3]."""
     h, w, _ = grid.shape
     x = (grid.reshape(-1, 2) - 0.5) * 2
     depth = len(params) // 2
@@ -89,7 +90,7 @@ def forward(params: Sequence[torch.Tensor], grid: torch.Tensor, first_omega_0: f
     for l in range(depth):
         z = torch.addmm(params[2 * l + 1], x, params[2 * l].t())
         om = first_omega_0 if l == 0 else hidden_omega_0
-        x = torch.sin(z * om) if l < depth - 1 else z
+        x = torch.sin(z * om) if (l < depth - 1 or not outermost_linear) else z
         if keep:
             zs.append(z); acts.append(x)
     pred = (x / 2 + 0.5).reshape(h, w, -1)
@@ -97,17 +98,20 @@ def forward(params: Sequence[torch.Tensor], grid: torch.Tensor, first_omega_0: f
 
 
 def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torch.Tensor,
-                   first_omega_0: float = 50.0, hidden_omega_0: float = 30.0, n_total: int = None):
+                   first_omega_0: float = 50.0, hidden_omega_0: float = 30.0, n_total: int = None,
+                   outermost_linear: bool = True):
     """F.mse_loss(pred, img) (mean over 3*N, train_helper.py:151-154) and its gradient w.r.t. every
     parameter, by explicit back-propagation (what autograd computes at train_helper.py:159-161).
     n_total: pixel count of the FULL image when `grid`/`img` are a row shard (pixel-split mode)."""
-    pred, acts, zs = forward(params, grid, first_omega_0, hidden_omega_0, keep=True)
+    pred, acts, zs = forward(params, grid, first_omega_0, hidden_omega_0, keep=True, outermost_linear=outermost_linear)
     depth = len(params) // 2
     n = grid.shape[0] * grid.shape[1]
     n_total = n if n_total is None else n_total
     resid = pred.reshape(n, -1) - img.reshape(n, -1)
     sse = float((resid.double() ** 2).sum())
     delta = resid * (2.0 / (3.0 * n_total)) * 0.5      # d mse/d pred * d(out/2+0.5)/d out
+    if not outermost_linear:
+        delta = delta * (hidden_omega_0 * torch.cos(zs[depth - 1] * hidden_omega_0))
     grads = [None] * (2 * depth)
     for l in range(depth - 1, -1, -1):
         grads[2 * l] = delta.t() @ acts[l]

@@ -6,6 +6,7 @@
 
   wide_512x3_32.npz   seed-0 SIREN 512x3 on a 32x40 synthetic image: init, first-step loss / prediction /
                       dense gradients, and the 10-step Adam loss curve (train_epoch, lr 3e-4)
+  sine_out_64x3_16.npz  the same quantities for SIREN 64x3 with outermost_linear=False (sine output layer) on 16x20
 """
 import os
 import sys
@@ -17,10 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import make_golden as mg  # noqa: E402
 
 
-def main():
-    th, siren, data, _ = mg.import_reference()
-    mlp = dict(first_omega_0=50.0, hidden_omega_0=30.0, outermost_linear=True)
-    hidden, depth, H, W = 512, 3, 32, 40
+def mint(th, siren, data, name, hidden, depth, H, W, outermost_linear):
+    mlp = dict(first_omega_0=50.0, hidden_omega_0=30.0, outermost_linear=outermost_linear)
     img = mg.synthetic_image(H, W, seed=7)
     grid = data.get_grid(H, W)
     torch.manual_seed(0)
@@ -34,9 +33,15 @@ def main():
     m.zero_grad()
     optim, sched = th.get_optimizer_lr_scheduler(m, mg.Cfg(name="adam", lr=3e-4))
     ls = [th.train_epoch(m, optim, grid, img, lr_scheduler=sched) for _ in range(10)]
-    np.savez_compressed(f"{mg.OUT}/wide_512x3_32.npz", init=p0, loss=loss.item(), grads=grads,
+    np.savez_compressed(f"{mg.OUT}/{name}.npz", init=p0, loss=loss.item(), grads=grads,
                         pred=pred.detach().numpy(), img=img.numpy(), losses=np.array(ls, np.float64))
-    print("wide_512x3_32: loss %.6f -> %.6f" % (ls[0], ls[-1]))
+    print("%s: loss %.6f -> %.6f" % (name, ls[0], ls[-1]))
+
+
+def main():
+    th, siren, data, _ = mg.import_reference()
+    mint(th, siren, data, "wide_512x3_32", 512, 3, 32, 40, True)
+    mint(th, siren, data, "sine_out_64x3_16", 64, 3, 16, 20, False)
 
 
 if __name__ == "__main__":

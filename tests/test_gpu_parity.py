@@ -520,3 +520,27 @@ def test_train_steps_bulk_equals_step_by_step(with_mask):
     assert lra == lrb and ra == rb and sa == sb
     for x, y in zip(pa + ma, pb + mb):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("hidden,depth,H,W", [(64, 3, 16, 20), (512, 3, 12, 40)])
+def test_sine_output_layer(golden, hidden, depth, H, W):
+    """outermost_linear=False (siren.py:110-117): the output layer is a sine too.  64x3 against the reference's
+    golden vector (incl. its 10-step loss curve), 512x3 (wide kernels) against the oracle."""
+    if hidden == 64:
+        d = golden("sine_out_64x3_16")
+        p, img = so.unflatten(d["init"], hidden, depth), torch.tensor(d["img"])
+    else:
+        p, img = so.siren_init(hidden, depth, seed=2), so.synthetic_image(H, W, seed=6)
+    grid = so.get_grid(H, W)
+    eng = _engine(H, W, hidden, depth, "f16", p, img, outermost_linear=False)
+    pred, sse = eng.forward()
+    assert np.abs(pred.cpu().numpy() - so.forward(p, grid, outermost_linear=False).numpy()).max() <= 6e-4
+    loss, sse_ref, grads = so.loss_and_grads(p, grid, img, outermost_linear=False)
+    assert abs(sse - sse_ref) <= 3e-3 * sse_ref
+    eng.forward_backward()
+    g, ref = eng.get_grads().cpu().numpy(), so.flatten(grads)
+    assert np.linalg.norm(g - ref) <= 6e-3 * np.linalg.norm(ref)
+    if hidden == 64:
+        assert np.linalg.norm(g - d["grads"]) <= 6e-3 * np.linalg.norm(d["grads"])
+        losses = np.array(eng.step([3e-4] * 10, want_loss=True))
+        assert np.abs(losses / d["losses"] - 1).max() <= 2e-2

@@ -35,6 +35,19 @@ def test_first_step_loss_and_gradients(golden):
         assert np.abs(so.forward(p, grid).numpy() - d["pred"]).max() <= 2e-6
 
 
+def test_sine_output_layer(golden):
+    """outermost_linear=False: first-step loss / prediction / gradients of the oracle against the reference."""
+    d = golden("sine_out_64x3_16")
+    H, W, _ = d["img"].shape
+    p = so.unflatten(d["init"], 64, 3)
+    assert np.array_equal(so.flatten(so.siren_init(64, 3, seed=0)), d["init"])
+    grid, img = so.get_grid(H, W), torch.tensor(d["img"])
+    loss, _, grads = so.loss_and_grads(p, grid, img, outermost_linear=False)
+    assert abs(loss - float(d["loss"])) <= 1e-6 * float(d["loss"])
+    assert np.linalg.norm(so.flatten(grads) - d["grads"]) <= 2e-6 * np.linalg.norm(d["grads"])
+    assert np.abs(so.forward(p, grid, outermost_linear=False).numpy() - d["pred"]).max() <= 2e-6
+
+
 def test_wide_short_run(golden):
     """512x3 (wide path fixture): 10 Adam steps of the oracle against the reference's loss curve."""
     d = golden("wide_512x3_32")
