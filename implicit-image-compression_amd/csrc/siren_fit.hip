@@ -319,15 +319,23 @@ int refresh_images_wide(sf_engine* h) {
 
 template <int MODE>
 int launch_wgemm(sf_engine* h, const WGemmArgs& a, int n_super, int n_ob) {
-  const size_t lds = (size_t)4 * (MODE == 1 ? 1 : 8) * 4 * 1024 + 64;
   const bool f16 = h->cfg.compute_dtype == SF_F16;
-  int rc = f16 ? set_lds(k_wgemm<MODE, OpF16>, lds) : set_lds(k_wgemm<MODE, OpBF16>, lds);
-  if (rc) return rc;
   WGemmArgs b = a;
   b.n_super = n_super; b.n_ob = n_ob;
   const unsigned grid = (unsigned)((n_super + 7) / 8 * 8 * n_ob);
-  if (f16) hipLaunchKernelGGL((k_wgemm<MODE, OpF16>), dim3(grid), dim3(512), lds, h->stream, b);
-  else hipLaunchKernelGGL((k_wgemm<MODE, OpBF16>), dim3(grid), dim3(512), lds, h->stream, b);
+  if constexpr (MODE == 1) {
+    const size_t lds = (size_t)4 * 4 * 1024 + 64;
+    int rc = f16 ? set_lds(k_wgemm<1, OpF16>, lds) : set_lds(k_wgemm<1, OpBF16>, lds);
+    if (rc) return rc;
+    if (f16) hipLaunchKernelGGL((k_wgemm<1, OpF16>), dim3(grid), dim3(512), lds, h->stream, b);
+    else hipLaunchKernelGGL((k_wgemm<1, OpBF16>), dim3(grid), dim3(512), lds, h->stream, b);
+  } else {
+    const size_t lds = (size_t)4 * 32 * 1024;
+    int rc = f16 ? set_lds(k_wgemm2<MODE, OpF16>, lds) : set_lds(k_wgemm2<MODE, OpBF16>, lds);
+    if (rc) return rc;
+    if (f16) hipLaunchKernelGGL((k_wgemm2<MODE, OpF16>), dim3(grid), dim3(512), lds, h->stream, b);
+    else hipLaunchKernelGGL((k_wgemm2<MODE, OpBF16>), dim3(grid), dim3(512), lds, h->stream, b);
+  }
   HIPCHK(hipGetLastError());
   return SF_OK;
 }
@@ -709,7 +717,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->p_stride * 16);
   if (h->wide) ALLOC(h->Abuf, (size_t)(D - 1) * h->p_stride * 16);
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
-  { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4); }
+  { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4 + 4096); }
   h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
   ALLOC(h->sse_part, h->n_sse * 4); ALLOC(h->sse_dev, 8);
 #undef ALLOC
@@ -725,6 +733,18 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
 int sf_destroy(sf_handle* h) {
   if (!h) return SF_OK;
   if (h->stream || true) hipStreamSynchronize(h->stream);
+#ifdef SF_EXPERIMENT_STAMP
+  if (h->wide) {
+    unsigned long long dbg[32];
+    const size_t sw = 256;
+    hipMemcpy(dbg, (char*)h->slab + (size_t)h->dw_wg * (sw * sw + sw) * 4, sizeof(dbg), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 8; ++i)
+      if (dbg[i * 4 + 3])
+        fprintf(stderr, "stamp wg(x%d,y%d) wave%d: per block wait %.0f stage %.0f compute %.0f cycles (100 MHz ticks x?) nblk %llu\n",
+                (i >> 2) ? 5 : 0, ((i >> 1) & 1) ? 9 : 0, (i & 1) ? 7 : 0, (double)dbg[i * 4] / dbg[i * 4 + 3],
+                (double)dbg[i * 4 + 1] / dbg[i * 4 + 3], (double)dbg[i * 4 + 2] / dbg[i * 4 + 3], dbg[i * 4 + 3]);
+  }
+#endif
   for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab,
                   h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part, h->biasw, h->Abuf,

@@ -126,12 +126,25 @@ DEV void bar_dma() {
   asm volatile("" ::: "memory");
 }
 
+// LDS-DMA of one 1 KiB piece: lane i's 16 bytes at gsrc (per-lane address) -> LDS lds_wave_base + 16 i.
+// Issued as inline asm, NOT through __builtin_amdgcn_global_load_lds: hipcc's waitcnt pass knows that the
+// builtin writes LDS and, unable to tell which bytes, puts an s_waitcnt vmcnt(0) in front of the next LDS read
+// it has a memory operand for (every ds_read_b64_tr_b16 intrinsic) - inside the ring loops that drained the
+// prefetch issued a few instructions earlier on every iteration.  The kernels order DMA against LDS reads
+// themselves (counted vmcnt + s_barrier in bar_dma / bar_all), which is the only synchronisation wanted.
 DEV void glds16(const void* gsrc, char* lds_wave_base) {
 #ifdef SF_EXPERIMENT_NO_DMA    // timing-only build: no LDS-DMA traffic (kernels compute on stale LDS)
   return;
 #endif
+#ifdef SF_EXPERIMENT_BUILTIN_DMA
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#else
+  const uint32_t lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(lds), "v"(gsrc) : "memory", "m0");
+#endif
 }
 
 
@@ -361,12 +374,25 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
 // ds_read_b64_tr_b16 for fragment tile `tile` (32 neurons), pixel k-step kk (16 pixels), half-read u.
 // Returned fragment: lane (r = lane&31 -> neuron 32*tile + r, hq = lane>>5), elements = pixels
 // 16*kk + 8*hq + 4*u + {0..3}.
+// Bank swizzle of every LDS block that is read transposed.  A piece copied verbatim (slot = register-image
+// lane h*32 + m) puts the four 64-byte regions a 32-lane half of ds_read_b64_tr_b16 touches (two k-step pieces
+// x two lane halves h) 512 / 1024 bytes apart, i.e. on the SAME 16 of the 64 banks: a 4-way conflict on every
+// transposed read (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE in the unswizzled k_bwd).  Stored at slot
+// h*32 + (m ^ 4h ^ 8*(k-step parity)) the four regions land on the four different bank quarters, and the
+// lane-linear ds_read_b128 of the same piece stays conflict-free (an XOR by a multiple of 4 only permutes the
+// 4-lane clusters inside each of the instruction's lane groups).  global_load_lds writes LDS lane-linearly but
+// takes a per-lane GLOBAL address, so the permutation costs nothing: LDS slot i fetches global slot sw_lane(i).
+DEV int sw_lane(int l, int parity) { return l ^ ((l >> 5) << 2) ^ (parity << 3); }
+
 DEV int tr_addr(int tile, int kk, int u, int lane) {
   const int g = lane >> 4, gs = g & 1, hq = g >> 1, li = lane & 15, q = li >> 2, p = li & 3;
   const int mpix = 16 * kk + 8 * hq + 4 * u + q;
-  const int piece = (2 * tile + gs) * 64 + (p & 1) * 32 + mpix;
+  const int piece = (2 * tile + gs) * 64 + (p & 1) * 32 + (mpix ^ ((p & 1) << 2) ^ (gs << 3));
   return piece * 16 + 8 * (p >> 1);
 }
+// lane part of tr_addr (tile 0, k-step 0, half-read 0); tile adds 2048, k-step 256, and half-read 1 is the
+// same address with bit 6 flipped (the swizzle XORs the bit the half-read index would otherwise add)
+DEV int tr_lane_base(int lane) { return tr_addr(0, 0, 0, lane); }
 
 DEV u32x4 ds_read_tr_pair(const char* base, int off0, int off1) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -374,6 +400,11 @@ DEV u32x4 ds_read_tr_pair(const char* base, int off0, int off1) {
   const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
   const u32x2 a0 = __builtin_bit_cast(u32x2, r0), a1 = __builtin_bit_cast(u32x2, r1);
   return u32x4{a0.x, a0.y, a1.x, a1.y};
+}
+// fragment (tile, kk) of the F-layout block at `blk`: trb = tr_lane_base(lane)
+DEV u32x4 ds_read_tr_frag(const char* blk, int trb, int tile, int kk) {
+  const int a0 = trb + tile * 2048 + kk * 256;
+  return ds_read_tr_pair(blk, a0, a0 ^ 64);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,6 +458,8 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WAVES_C, wc = wave % WAVES_C;
   const int xit0 = wave * XT;
+  const int trb = tr_lane_base(lane);
+  const int lsw = sw_lane(lane, 0);      // slot of this lane's register image in an even piece; odd: lsw ^ 8
 
   // stationary W^T rows of this wave: k-steps [0, KSR) in registers, [KSR, KSX) parked in LDS behind the ring
   // (the widest configuration needs the 32 registers: 256 accumulator + 128 weight registers leave too few)
@@ -460,9 +493,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   auto stage = [&](int k) {   // block k of this workgroup -> ring slot k % NB, one 1 KiB piece per wave-instruction
     char* base = smem + (k % NB) * BLK;
     const long pb = pb_begin + k * pb_step;
-    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * KSJ + pc) * 64 + lane, base + pc * 1024);
+    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * KSJ + pc) * 64 + (lsw ^ ((pc & 1) << 3)), base + pc * 1024);
     if (!P0)
-      for (int pc = wave; pc < KSI; pc += NW) glds16(a.P + (pb * KSI + pc) * 64 + lane, base + (KSJ + pc) * 1024);
+      for (int pc = wave; pc < KSI; pc += NW)
+        glds16(a.P + (pb * KSI + pc) * 64 + (lsw ^ ((pc & 1) << 3)), base + (KSJ + pc) * 1024);
   };
   // P0: layer-0 table in LDS (behind the parked weights) and this lane's pixel coordinates per block
   const f32x4* sL0 = reinterpret_cast<const f32x4*>(smem + NB * BLK + (size_t)NW * XT * WSP * 1024);
@@ -497,7 +531,8 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   auto x_load = [&](int k, int c, u32x4* dst) {
     const char* sD = smem + (k % NB) * BLK;
 #pragma unroll
-    for (int i = 0; i < XS; ++i) dst[i] = reinterpret_cast<const u32x4*>(sD + (c * XS + i) * 1024)[lane];
+    for (int i = 0; i < XS; ++i)
+      dst[i] = reinterpret_cast<const u32x4*>(sD + (c * XS + i) * 1024)[lsw ^ (((c * XS + i) & 1) << 3)];
   };
   auto x_mma_chunk = [&](int x, int c, const u32x4* b, f32x16& g) {
 #pragma unroll
@@ -515,7 +550,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   auto x_epi_sub = [&](int k, int x, int e, const f32x16& g) {
     char* sP = smem + (k % NB) * BLK + KSJ * 1024;
     const int q = e >> 1, hf = e & 1, ks = 2 * (xit0 + x) + q;
-    u32x4* pp = reinterpret_cast<u32x4*>(sP + ks * 1024) + lane;
+    u32x4* pp = reinterpret_cast<u32x4*>(sP + ks * 1024) + (lsw ^ ((q & 1) << 3));   // ks = 2*tile + q
     if (!P0 && hf == 0) ep_p = *pp;
 #pragma unroll
     for (int j2 = 2 * hf; j2 < 2 * hf + 2; ++j2) {
@@ -541,13 +576,13 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   };
   auto wa_load = [&](int k, int kk, int x) -> u32x4 {   // delta^T fragment (rows = neurons of this wave's tile x)
     const char* sD = smem + (k % NB) * BLK;
-    return ds_read_tr_pair(sD, tr_addr(wr * WJ + x, kk, 0, lane), tr_addr(wr * WJ + x, kk, 1, lane));
+    return ds_read_tr_frag(sD, trb, wr * WJ + x, kk);
   };
   auto wb_load = [&](int k, int kk, u32x4* dst) {       // activation fragments (cols = this wave's WI tiles)
     const char* sP = smem + (k % NB) * BLK + KSJ * 1024;
 #pragma unroll
     for (int y = 0; y < WI; ++y)
-      dst[y] = ds_read_tr_pair(sP, tr_addr(wc * WI + y, kk, 0, lane), tr_addr(wc * WI + y, kk, 1, lane));
+      dst[y] = ds_read_tr_frag(sP, trb, wc * WI + y, kk);
   };
   auto w_mma_chunk = [&](int x, const u32x4& fa, const u32x4* fb) {
 #pragma unroll
@@ -671,10 +706,12 @@ __global__ __launch_bounds__(JW * 2) void k_dw0(Dw0Args a) {
   const int nblk = (int)((a.n_pb - pb_begin + pb_step - 1) / pb_step);
   f32x16 acc = {};
   float dbs = 0.f;
+  const int trb = tr_lane_base(lane);
   auto stage = [&](int k) {
     char* base = smem + (k % NB) * BLK;
     const long pb = pb_begin + k * pb_step;
-    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * a.ks_total + a.ks_off + pc) * 64 + lane, base + pc * 1024);
+    for (int pc = wave; pc < KSJ; pc += NW)
+      glds16(a.D + (pb * a.ks_total + a.ks_off + pc) * 64 + sw_lane(lane, pc & 1), base + pc * 1024);
   };
   // B operand = coordinates of the block's 32 pixels as 16-bit columns {x0_hi, x0_lo, x1_hi, x1_lo}.  Wave 0
   // builds a [4][32] table per block (one pixel per lane, one integer division), double-buffered by block
@@ -711,8 +748,8 @@ __global__ __launch_bounds__(JW * 2) void k_dw0(Dw0Args a) {
     if (k + 1 < nblk) build_xy(k + 1);
     const u32x4 fb0 = coord_frag(k, 0), fb1 = coord_frag(k, 1);
     const char* sD = smem + (k & (NB - 1)) * BLK;
-    const u32x4 fa0 = ds_read_tr_pair(sD, tr_addr(wave, 0, 0, lane), tr_addr(wave, 0, 1, lane));
-    const u32x4 fa1 = ds_read_tr_pair(sD, tr_addr(wave, 1, 0, lane), tr_addr(wave, 1, 1, lane));
+    const u32x4 fa0 = ds_read_tr_frag(sD, trb, wave, 0);
+    const u32x4 fa1 = ds_read_tr_frag(sD, trb, wave, 1);
     acc = OP::mfma(fa0, fb0, acc);
     acc = OP::mfma(fa1, fb1, acc);
     float t = 0.f;

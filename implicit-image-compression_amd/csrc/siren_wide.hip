@@ -289,6 +289,115 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
   }
 }
 
+// k_wgemm2 (MODE 0 / 2): same product and epilogues as k_wgemm, but BOTH operands go through the LDS ring:
+// a 256x256 tile needs 128 flop per operand byte, so at the MFMA peak the CUs would pull ~20 TB/s out of L2;
+// loading the 256-pixel input chunk once per workgroup (instead of once per wave pair, in registers) cuts the
+// L2 -> CU bytes by a third.  Chunk = 2 k-steps: 16 A pieces + 16 B pieces = 32 KiB per slot, 4 slots, staged
+// three chunks ahead (4 LDS-DMA instructions per wave per chunk, counted vmcnt).
+template <int MODE, typename OP>
+__global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
+  static_assert(MODE == 0 || MODE == 2, "last layer: k_wgemm<1>");
+  constexpr int OT = 8, TW = 4, PBW = 2, NB = 4, PD = 3, SLOT = 32 * 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int ob = q % a.n_ob;
+  const int sb = (q / a.n_ob) * 8 + xcd;
+  if (sb >= a.n_super) return;
+  const int t0 = TW * (wave & 1), pw = 2 * (wave >> 1);
+  const long pbg = (long)sb * kWavesFwd;                 // first pixel block of the workgroup
+  const long pb0 = pbg + pw;
+  const u32x4* Ablk = a.A + (size_t)ob * a.a_block_pieces * 64;
+  const int n2 = a.ks_in / 2;                            // chunks of 2 k-steps
+  auto stage = [&](int c) {
+    char* base = smem + (c % NB) * SLOT;
+    // A piece (ot, s2) of chunk c lives at image piece ((c>>1)*OT + ot)*4 + 2*(c&1) + s2 ; B piece (p, s2)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 8 * i, ot = pc >> 1, s2 = pc & 1;
+      glds16(Ablk + ((size_t)((c >> 1) * OT + ot) * 4 + 2 * (c & 1) + s2) * 64 + lane, base + pc * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 8 * i, p = pc >> 1, s2 = pc & 1;
+      glds16(a.Bin + ((pbg + p) * a.ks_in + 2 * c + s2) * 64 + lane, base + (16 + pc) * 1024);
+    }
+  };
+  f32x16 acc[TW][PBW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    f32x16 init = f32x16{};
+    if (MODE == 0) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&a.bias[(ob * OT + t0 + t) * 32 + 8 * q4 + 4 * h]);
+        init[4 * q4 + 0] = b.x; init[4 * q4 + 1] = b.y; init[4 * q4 + 2] = b.z; init[4 * q4 + 3] = b.w;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PBW; ++p) acc[t][p] = init;
+  }
+  asm volatile("" ::"v"(acc[0][0][0]));                  // bias loads retire before the first DMA is issued
+  for (int c = 0; c < PD && c < n2; ++c) stage(c);
+  for (int c = 0; c < n2; ++c) {
+    if (c + 2 < n2) bar_dma<8>(); else if (c + 1 < n2) bar_dma<4>(); else bar_all();
+    if (c + PD < n2) stage(c + PD);
+    asm volatile("" ::: "memory");
+    const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
+    const u32x4* sB = sA + 16 * 64;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      u32x4 b[PBW];
+#pragma unroll
+      for (int p = 0; p < PBW; ++p) b[p] = sB[((pw + p) * 2 + s2) * 64];
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        const u32x4 fa = sA[((t0 + t) * 2 + s2) * 64];
+#pragma unroll
+        for (int p = 0; p < PBW; ++p) acc[t][p] = OP::mfma(fa, b[p], acc[t][p]);
+      }
+    }
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int p = 0; p < PBW; ++p)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          float ph[8], av[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float tt = acc[t][p][8 * qq + j] * a.sc;
+            ph[j] = __builtin_amdgcn_fractf(tt);
+            av[j] = __builtin_amdgcn_sinf(tt);
+          }
+          const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane;
+          a.Out[pidx] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
+                              pack_phase2(ph[6], ph[7])};
+          a.OutAct[pidx] = u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]),
+                                 OP::pack2(av[6], av[7])};
+        }
+  } else {
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int p = 0; p < PBW; ++p)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane;
+          const u32x4 pv = a.Pprev[pidx];
+          u32x4 o;
+#pragma unroll
+          for (int j2 = 0; j2 < 4; ++j2)
+            o[j2] = OP::pack2(acc[t][p][8 * qq + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(pv[j2])),
+                              acc[t][p][8 * qq + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(pv[j2])));
+          a.Out[pidx] = o;
+        }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_wdw: [JW x 256] blocks of a weight gradient: dW[jb-block][ib-block] = delta[:, jb]^T * act[:, ib]
 //   ring of 32-pixel blocks as in k_bwd; both operands are read transposed (ds_read_b64_tr_b16).
@@ -311,6 +420,7 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WAVES_C, wc = wave % WAVES_C;
+  const int trb = tr_lane_base(lane);
   // all blocks of one layer run in ONE launch; workgroups with the same blockIdx.x stream the same pixel blocks
   // (of different column blocks) at the same time and sit on the same XCD (gridDim.x is a multiple of 8), so
   // each delta / phase piece is pulled from HBM once and served to the other readers by that XCD's L2
@@ -329,15 +439,25 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
   auto stage = [&](int k) {
     char* base = smem + (k % NB) * BLK;
     const long pb = pb_begin + k * pb_step;
-    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * a.ksd_total + ksd_off + pc) * 64 + lane, base + pc * 1024);
-    for (int pc = wave; pc < KSI; pc += NW) glds16(a.P + (pb * a.ksp_total + ksp_off + pc) * 64 + lane, base + (KSJ + pc) * 1024);
+    for (int pc = wave; pc < KSJ; pc += NW)
+      glds16(a.D + (pb * a.ksd_total + ksd_off + pc) * 64 + sw_lane(lane, pc & 1), base + pc * 1024);
+    for (int pc = wave; pc < KSI; pc += NW)
+      glds16(a.P + (pb * a.ksp_total + ksp_off + pc) * 64 + sw_lane(lane, pc & 1), base + (KSJ + pc) * 1024);
   };
   for (int k = 0; k < PD && k < nblk; ++k) stage(k);
+#ifdef SF_EXPERIMENT_STAMP   // timing-only build: where one wave's block step goes (wait / DMA issue / compute)
+  unsigned long long st_wait = 0, st_stage = 0, st_comp = 0, st_t = __builtin_amdgcn_s_memtime();
+#define SF_STAMP(acc_) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - st_t; st_t = n_; } while (0)
+#else
+#define SF_STAMP(acc_) do {} while (0)
+#endif
   for (int k = 0; k < nblk; ++k) {
     // block k landed (blocks k+1, k+2 stay in flight), everyone finished block k-1 (whose slot is refilled next)
     if (G > 0 && k + PD - 1 < nblk) bar_dma<(PD - 1) * G>(); else bar_all();
+    SF_STAMP(st_wait);
     if (k + PD < nblk) stage(k + PD);
     asm volatile("" ::: "memory");
+    SF_STAMP(st_stage);
     char* sD = smem + (k % NB) * BLK;
     char* sP = sD + KSJ * 1024;
 #pragma unroll
@@ -345,10 +465,10 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
       u32x4 fa[WJ], fb[WI];
 #pragma unroll
       for (int x = 0; x < WJ; ++x)
-        fa[x] = ds_read_tr_pair(sD, tr_addr(wr * WJ + x, kk, 0, lane), tr_addr(wr * WJ + x, kk, 1, lane));
+        fa[x] = ds_read_tr_frag(sD, trb, wr * WJ + x, kk);
 #pragma unroll
       for (int y = 0; y < WI; ++y)
-        fb[y] = ds_read_tr_pair(sP, tr_addr(wc * WI + y, kk, 0, lane), tr_addr(wc * WI + y, kk, 1, lane));
+        fb[y] = ds_read_tr_frag(sP, trb, wc * WI + y, kk);
 #pragma unroll
       for (int x = 0; x < WJ; ++x)
 #pragma unroll
@@ -363,7 +483,18 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
         }
       }
     }
+#ifdef SF_EXPERIMENT_STAMP
+    asm volatile("s_nop 0" :: "v"(acc[0][0][0]));   // MFMA results of this step consumed -> chain finished
+#endif
+    SF_STAMP(st_comp);
   }
+#ifdef SF_EXPERIMENT_STAMP
+  if (JW == 256 && lane == 0 && (wave == 0 || wave == 7) && (blockIdx.x == 0 || blockIdx.x == 5) && (blockIdx.y == 0 || blockIdx.y == 9)) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.slab + (size_t)gridDim.y * gridDim.x * (JW * 256 + JW));
+    const int slot = ((blockIdx.x != 0) * 2 + (blockIdx.y != 0)) * 2 + (wave != 0);
+    dbg[slot * 4 + 0] = st_wait; dbg[slot * 4 + 1] = st_stage; dbg[slot * 4 + 2] = st_comp; dbg[slot * 4 + 3] = nblk;
+  }
+#endif
   float* slab = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (JW * 256 + JW);
   const int cl = lane & 31, hh = lane >> 5;
 #pragma unroll
