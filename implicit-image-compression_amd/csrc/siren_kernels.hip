@@ -146,6 +146,17 @@ DEV void glds16(const void* gsrc, char* lds_wave_base) {
                :: "s"(lds), "v"(gsrc) : "memory", "m0");
 #endif
 }
+// same, with the address split into a wave-uniform base (SGPR pair) and a per-lane byte offset (one VGPR):
+// no 64-bit per-lane address arithmetic, and nothing but the lane offset has to stay live in VGPRs
+DEV void glds16s(const void* sbase, uint32_t lane_off_bytes, char* lds_wave_base) {
+#ifdef SF_EXPERIMENT_NO_DMA
+  return;
+#endif
+  const uint32_t lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(lds), "v"(lane_off_bytes), "s"(sbase) : "memory", "m0");
+}
 
 
 // ---------------------------------------------------------------------------------------------
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
 
   // async copy of `n` image pieces (1 KiB each) into LDS pieces [dst, dst+n), spread over the 8 waves
   auto stage = [&](const u32x4* src, int dst, int n) {
-    for (int pc = wave; pc < n; pc += kWavesFwd) glds16(src + pc * 64 + lane, smem + (size_t)(dst + pc) * 1024);
+    for (int pc = wave; pc < n; pc += kWavesFwd) glds16s(src + pc * 64, (uint32_t)lane * 16u, smem + (size_t)(dst + pc) * 1024);
   };
   for (int i = tid; i < WD; i += 512) sL0[i] = a.l0tab[i];
   const long pb = (long)blockIdx.x * kWavesFwd + wave;  // pixel block inside the chunk
@@ -460,6 +471,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   const int xit0 = wave * XT;
   const int trb = tr_lane_base(lane);
   const int lsw = sw_lane(lane, 0);      // slot of this lane's register image in an even piece; odd: lsw ^ 8
+  const uint32_t lswb = (uint32_t)lsw * 16u;   // the same as a byte offset; odd: lswb ^ 128
 
   // stationary W^T rows of this wave: k-steps [0, KSR) in registers, [KSR, KSX) parked in LDS behind the ring
   // (the widest configuration needs the 32 registers: 256 accumulator + 128 weight registers leave too few)
@@ -493,10 +505,29 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
   auto stage = [&](int k) {   // block k of this workgroup -> ring slot k % NB, one 1 KiB piece per wave-instruction
     char* base = smem + (k % NB) * BLK;
     const long pb = pb_begin + k * pb_step;
-    for (int pc = wave; pc < KSJ; pc += NW) glds16(a.D + (pb * KSJ + pc) * 64 + (lsw ^ ((pc & 1) << 3)), base + pc * 1024);
+    for (int pc = wave; pc < KSJ; pc += NW) glds16s(a.D + (pb * KSJ + pc) * 64, lswb ^ ((pc & 1) << 7), base + pc * 1024);
     if (!P0)
-      for (int pc = wave; pc < KSI; pc += NW)
-        glds16(a.P + (pb * KSI + pc) * 64 + (lsw ^ ((pc & 1) << 3)), base + (KSJ + pc) * 1024);
+      for (int pc = wave; pc < KSI; pc += NW) glds16s(a.P + (pb * KSI + pc) * 64, lswb ^ ((pc & 1) << 7), base + (KSJ + pc) * 1024);
+  };
+  // the same pieces one at a time, to be issued BETWEEN the MFMAs of a step (an LDS-DMA instruction costs its wave
+  // ~150-200 issue cycles inside a burst of them, ~60 with MFMAs in flight): piece i of this wave for block k
+  constexpr int GD = KSJ / NW, GP = GD + (P0 ? 0 : KSI / NW);
+  // (k_wdw issues its pieces that way; here both placements tried - X chunks and W chunks - pushed the 256-register
+  //  8-wave build into scratch spills INSIDE the steady loop, whose reloads then drain the DMA queue, so the burst
+  //  at the top of the step stays)
+  constexpr bool SPREAD = false && (KSJ % NW == 0) && (P0 || KSI % NW == 0) && GP <= 2 * WJ;
+  auto stage_piece = [&](int k, int i) {
+    // past the last block the SAME ring slot is refilled with the last block again: the slot is free (its block
+    // was consumed NB - PD steps ago), the bytes are never read, and the steady loop stays branch-free
+    char* base = smem + (k % NB) * BLK;
+    const long pb = pb_begin + (long)(k < nblk ? k : nblk - 1) * pb_step;
+    if (i < GD) {
+      const int pc = wave + NW * i;
+      glds16s(a.D + (pb * KSJ + pc) * 64, lswb ^ ((pc & 1) << 7), base + pc * 1024);
+    } else {
+      const int pc = wave + NW * (i - GD);
+      glds16s(a.P + (pb * KSI + pc) * 64, lswb ^ ((pc & 1) << 7), base + (KSJ + pc) * 1024);
+    }
   };
   // P0: layer-0 table in LDS (behind the parked weights) and this lane's pixel coordinates per block
   const f32x4* sL0 = reinterpret_cast<const f32x4*>(smem + NB * BLK + (size_t)NW * XT * WSP * 1024);
@@ -594,7 +625,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
       dbs[x] += tsum;
     }
   };
-  auto step = [&](int kx, bool do_x, bool do_w) {
+  auto step = [&](int kx, bool do_x, bool do_w, bool do_s) {   // do_s: issue the LDS-DMA of block kx+PD inside the X chunks
     u32x4 xb[2][XS];            // X B-operand pieces, double-buffered
     u32x4 fb[2][WI], fa[2];     // W operands: activation fragments per k-step (2 sets), delta^T fragment (2 sets)
     f32x16 gp = {}, gc = {};
@@ -632,6 +663,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
           if (x + 1 < WJ) fa[(i + 1) & 1] = wa_load(kx - 1, kk, x + 1);
           else if (kk == 0) { wb_load(kx - 1, 1, fb[1]); fa[(i + 1) & 1] = wa_load(kx - 1, 1, 0); }
           w_mma_chunk(x, fa[i & 1], fb[kk]);
+          if (SPREAD && do_s && i < GP) stage_piece(kx + PD, i);   // W chunks: fewest live registers of the step
         }
         if (do_x && kk == 0) {
 #pragma unroll
@@ -646,17 +678,17 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd(BwdLayerArgs a) {
     bar_all();                          // block 0 landed
     if (PD < nblk) stage(PD);
     asm volatile("" ::: "memory");
-    step(0, true, false);
+    step(0, true, false, false);
     for (int k = 1; k < nblk; ++k) {
       // block k landed (requested PD steps ago; younger in the in-order vmcnt queue: the delta stores of the PD
       // steps since, and the DMA of blocks k+1 .. k+PD-1) and every wave finished step k-1
       if (k >= PD && k + PD - 1 < nblk) bar_dma<PD * S_ST + (PD - 1) * G_MIN>(); else bar_all();
-      if (k + PD < nblk) stage(k + PD);
+      if (!SPREAD && k + PD < nblk) stage(k + PD);
       asm volatile("" ::: "memory");
-      step(k, true, true);
+      step(k, true, true, true);
     }
     bar_lds();
-    step(nblk, false, true);
+    step(nblk, false, true, false);
   }
   float* slab = a.slab + (size_t)blockIdx.x * (JW * IW + JW);
   const int cl = lane & 31, hh = lane >> 5;
@@ -711,7 +743,7 @@ __global__ __launch_bounds__(JW * 2) void k_dw0(Dw0Args a) {
     char* base = smem + (k % NB) * BLK;
     const long pb = pb_begin + k * pb_step;
     for (int pc = wave; pc < KSJ; pc += NW)
-      glds16(a.D + (pb * a.ks_total + a.ks_off + pc) * 64 + sw_lane(lane, pc & 1), base + pc * 1024);
+      glds16s(a.D + (pb * a.ks_total + a.ks_off + pc) * 64, (uint32_t)sw_lane(lane, pc & 1) * 16u, base + pc * 1024);
   };
   // B operand = coordinates of the block's 32 pixels as 16-bit columns {x0_hi, x0_lo, x1_hi, x1_lo}.  Wave 0
   // builds a [4][32] table per block (one pixel per lane, one integer division), double-buffered by block

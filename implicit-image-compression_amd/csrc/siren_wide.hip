@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
   const u32x4* Ablk = a.A + (size_t)ob * a.a_block_pieces * 64;
   auto stage = [&](int c) {
     char* base = smem + (c % NB) * CH;
-    for (int pc = wave; pc < OT * 4; pc += kWavesFwd) glds16(Ablk + ((size_t)c * OT * 4 + pc) * 64 + lane, base + pc * 1024);
+    for (int pc = wave; pc < OT * 4; pc += kWavesFwd) glds16s(Ablk + ((size_t)c * OT * 4 + pc) * 64, (uint32_t)lane * 16u, base + pc * 1024);
   };
   f32x16 acc[TW][PBW];
 #pragma unroll
@@ -316,12 +316,12 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pc = wave + 8 * i, ot = pc >> 1, s2 = pc & 1;
-      glds16(Ablk + ((size_t)((c >> 1) * OT + ot) * 4 + 2 * (c & 1) + s2) * 64 + lane, base + pc * 1024);
+      glds16s(Ablk + ((size_t)((c >> 1) * OT + ot) * 4 + 2 * (c & 1) + s2) * 64, (uint32_t)lane * 16u, base + pc * 1024);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pc = wave + 8 * i, p = pc >> 1, s2 = pc & 1;
-      glds16(a.Bin + ((pbg + p) * a.ks_in + 2 * c + s2) * 64 + lane, base + (16 + pc) * 1024);
+      glds16s(a.Bin + ((pbg + p) * a.ks_in + 2 * c + s2) * 64, (uint32_t)lane * 16u, base + (16 + pc) * 1024);
     }
   };
   f32x16 acc[TW][PBW];
@@ -440,9 +440,9 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
     char* base = smem + (k % NB) * BLK;
     const long pb = pb_begin + k * pb_step;
     for (int pc = wave; pc < KSJ; pc += NW)
-      glds16(a.D + (pb * a.ksd_total + ksd_off + pc) * 64 + sw_lane(lane, pc & 1), base + pc * 1024);
+      glds16s(a.D + (pb * a.ksd_total + ksd_off + pc) * 64, (uint32_t)sw_lane(lane, pc & 1) * 16u, base + pc * 1024);
     for (int pc = wave; pc < KSI; pc += NW)
-      glds16(a.P + (pb * a.ksp_total + ksp_off + pc) * 64 + sw_lane(lane, pc & 1), base + (KSJ + pc) * 1024);
+      glds16s(a.P + (pb * a.ksp_total + ksp_off + pc) * 64, (uint32_t)sw_lane(lane, pc & 1) * 16u, base + (KSJ + pc) * 1024);
   };
   for (int k = 0; k < PD && k < nblk; ++k) stage(k);
 #ifdef SF_EXPERIMENT_STAMP   // timing-only build: where one wave's block step goes (wait / DMA issue / compute)
@@ -455,7 +455,23 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
     // block k landed (blocks k+1, k+2 stay in flight), everyone finished block k-1 (whose slot is refilled next)
     if (G > 0 && k + PD - 1 < nblk) bar_dma<(PD - 1) * G>(); else bar_all();
     SF_STAMP(st_wait);
-    if (k + PD < nblk) stage(k + PD);
+    // The LDS-DMA of block k+PD is issued BETWEEN the MFMAs of this block, one piece per group of MFMAs: an
+    // LDS-DMA instruction costs its wave ~150-200 issue cycles in a burst and ~60 among MFMAs.
+    const bool do_stage = k + PD < nblk;
+    char* nbase = smem + ((k + PD) % NB) * BLK;
+    const long npb = pb_begin + (long)(k + PD) * pb_step;
+    auto stage_piece = [&](int i) {     // i-th of this wave's G pieces of block k+PD
+      if (!do_stage) return;
+      constexpr int GD = KSJ / NW;      // delta pieces per wave
+      if (i < GD) {
+        const int pc = wave + NW * i;
+        glds16s(a.D + (npb * a.ksd_total + ksd_off + pc) * 64, (uint32_t)sw_lane(lane, pc & 1) * 16u, nbase + pc * 1024);
+      } else {
+        const int pc = wave + NW * (i - GD);
+        glds16s(a.P + (npb * a.ksp_total + ksp_off + pc) * 64, (uint32_t)sw_lane(lane, pc & 1) * 16u, nbase + (KSJ + pc) * 1024);
+      }
+    };
+    if (G == 0 && do_stage) stage(k + PD);
     asm volatile("" ::: "memory");
     SF_STAMP(st_stage);
     char* sD = smem + (k % NB) * BLK;
@@ -464,15 +480,19 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
     for (int kk = 0; kk < 2; ++kk) {
       u32x4 fa[WJ], fb[WI];
 #pragma unroll
-      for (int x = 0; x < WJ; ++x)
-        fa[x] = ds_read_tr_frag(sD, trb, wr * WJ + x, kk);
+      for (int x = 0; x < WJ; ++x) fa[x] = ds_read_tr_frag(sD, trb, wr * WJ + x, kk);
 #pragma unroll
-      for (int y = 0; y < WI; ++y)
-        fb[y] = ds_read_tr_frag(sP, trb, wc * WI + y, kk);
+      for (int y = 0; y < WI; ++y) fb[y] = ds_read_tr_frag(sP, trb, wc * WI + y, kk);
 #pragma unroll
-      for (int x = 0; x < WJ; ++x)
+      for (int x = 0; x < WJ; ++x) {
 #pragma unroll
         for (int y = 0; y < WI; ++y) acc[x][y] = OP::mfma(fa[x], fb[y], acc[x][y]);
+        if (G > 0 && (x & 1) == 1) {      // after every second row tile: 2 * WI MFMAs in flight behind the DMA issue
+          __builtin_amdgcn_sched_barrier(0);
+          stage_piece(kk * (WJ / 2) + (x >> 1));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       if (wc == 0) {
 #pragma unroll
         for (int x = 0; x < WJ; ++x) {
