@@ -198,8 +198,16 @@ int launch_bwd(sf_engine* h, bool last, bool p0, const BwdLayerArgs& a, int n_wg
       if (last) return launch_bwd_t<32, 256, 1, 8, true, 8>(h, a, n_wg, p0);
       // 8 waves (two per SIMD), all weight rows in registers, 5 x 32 KiB ring = 160 KiB: 96 KiB in flight;
       // the P0 variant needs more registers and keeps the 4-wave / 4-slot form
+#ifdef SF_EXPERIMENT_P0W8
+      return p0 ? launch_bwd_tp<256, 256, 2, 4, false, true, 4>(h, a, n_wg)
+#else
       return p0 ? launch_bwd_tp<256, 256, 2, 2, false, true, 4>(h, a, n_wg)
+#endif
+#ifdef SF_EXPERIMENT_NB4
+                : launch_bwd_tp<256, 256, 2, 4, false, false, 4>(h, a, n_wg);
+#else
                 : launch_bwd_tp<256, 256, 2, 4, false, false, 5>(h, a, n_wg);
+#endif
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }

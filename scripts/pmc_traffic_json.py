@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Assemble profiles/rNN_pmc_traffic_*.json from rocprofv3 --pmc passes over scripts/prof_step.py:
+
+    python scripts/pmc_traffic_json.py OUT.json DIR_FETCH DIR_WRITE [DIR_SQ ...]
+
+Per kernel: mean counter value per dispatch; hbm_bytes_per_launch = 2 * FETCH_SIZE KiB (gfx950 reports half of a
+wide coalesced stream, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+NAMES = [("k_fwd<256", "k_fwd"), ("k_bwd<32, 256", "k_bwd_last"), ("k_bwd<256, 256, 2, 4", "k_bwd_hidden"),
+         ("k_bwd<256, 256, 2, 2", "k_bwd_hidden_layer1"), ("k_dw0<256", "k_dw_first")]
+
+
+def main():
+    out, dirs = sys.argv[1], sys.argv[2:]
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    full = {}
+    for d in dirs:
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                for pat, short in NAMES:
+                    if pat in r["Kernel_Name"]:
+                        acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                        full[short] = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    kernels = {}
+    for k, cs in acc.items():
+        e = {"kernel": full[k]}
+        for c, v in sorted(cs.items()):
+            e[c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")] = sum(v) / len(v)
+        if "FETCH_SIZE_KiB" in e and "WRITE_SIZE_KiB" in e:
+            e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE_KiB"] + e["WRITE_SIZE_KiB"]) * 1024
+        kernels[k] = e
+    json.dump({"source": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | SQ_*} (separate passes) -- python3 scripts/prof_step.py 2048 2",
+               "note": "per launch at one 4 Mi-pixel chunk (2048x2048, SIREN 256x8): identical launch geometry to bench.py's "
+                       "4096x4096 run with 4 Mi-pixel chunks. FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 reports "
+                       "half of a wide coalesced stream, MI355X_MICROARCH.md HBM section).",
+               "kernels": kernels}, open(out, "w"), indent=1)
+    for k, e in kernels.items():
+        print(k, {c: round(v, 1) if isinstance(v, float) else v for c, v in e.items() if c != "kernel"})
+
+
+if __name__ == "__main__":
+    main()
