@@ -197,6 +197,11 @@ def main():
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": d["bytes_per_launch"],
                          "avg_launch_ms": avg_ms, "flops_per_launch": d["flops_per_launch"]},
+            # the same kernel against the HBM roof (it moves 1.5 KiB per pixel per layer: delta and phase in,
+            # delta out): algorithmic bytes per launch / launch time vs the 8 TB/s of MI355X_MICROARCH.md
+            "roofline_hbm": {"bound": "hbm", "kernel": dom, "achieved": d["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9,
+                             "peak": 8000.0, "unit": "GB/s",
+                             "frac": d["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic},
             "kernels": {k: {"ms_per_step": v["total_ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
                             "tflops": (v["flops_per_launch"] * v["launches"] / (v["total_ms"] * 1e-3) / 1e12)
                             if v["total_ms"] > 0 else 0.0,

@@ -279,12 +279,6 @@ double flops_fwd_px(const sf_engine* h) {
   const double W = h->WD;
   return 2.0 * (2 * W + (h->D - 2) * W * W + h->cfg.out_features * W);
 }
-double flops_bwdx_px_unused(const sf_engine* h) {
-  const double W = h->WD;
-  return 2.0 * ((h->D - 2) * W * W + h->cfg.out_features * W);
-}
-
-
 // ---------------------------------------------------------------------------------------------------------
 // wide path (hidden 512 / 1024): layer-at-a-time kernels of siren_wide.hip
 // ---------------------------------------------------------------------------------------------------------

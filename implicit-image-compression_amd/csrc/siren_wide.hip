@@ -126,12 +126,12 @@ struct WGemmArgs {
   int n_super, n_ob;     // 256-pixel super-blocks of the chunk, output blocks; grid = roundup(n_super, 8) * n_ob
 };
 
-// Workgroup = 8 waves = 256 pixels x one block of 256 output neurons (MODE 1: the 32 padded rows of the last
-// layer).  MODE 0/2: wave w owns the 64 pixels of pixel-block pair w>>1 and the 128 outputs of half w&1, so
-// every A fragment read from LDS feeds TWO MFMAs (LDS bytes per MFMA halved against one 32-pixel block per
-// wave; the 128 accumulator registers are the budget of an 8-wave workgroup).
+// k_wgemm<1>: the last layer (32 padded output rows) + residual.  Workgroup = 8 waves = 256 pixels, one
+// 32-pixel block per wave; the [32 x WD] weight image streams through a 4-slot LDS ring (4 k-steps per chunk),
+// the activations are prefetched two chunks ahead into registers.  (Hidden layers: k_wgemm2 below.)
 template <int MODE, typename OP>
 __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
+  static_assert(MODE == 1, "hidden layers and the data gradient run k_wgemm2");
   constexpr int OT = MODE == 1 ? 1 : 8;       // 32-row tiles per LDS chunk
   constexpr int TW = MODE == 1 ? 1 : 4;       // tiles per wave
   constexpr int PBW = MODE == 1 ? 1 : 2;      // pixel blocks per wave
@@ -216,44 +216,8 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { r0[p][i] = r1[p][i]; r1[p][i] = r2[p][i]; }
   }
-  // ---- epilogues ----
-  if (MODE == 0) {
-#pragma unroll
-    for (int t = 0; t < TW; ++t)
-#pragma unroll
-      for (int p = 0; p < PBW; ++p)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float ph[8], av[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float tt = acc[t][p][8 * q + j] * a.sc;
-            ph[j] = __builtin_amdgcn_fractf(tt);
-            av[j] = __builtin_amdgcn_sinf(tt);
-          }
-          const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + q) * 64 + lane;
-          a.Out[pidx] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
-                              pack_phase2(ph[6], ph[7])};
-          a.OutAct[pidx] = u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]),
-                                 OP::pack2(av[6], av[7])};
-        }
-  } else if (MODE == 2) {
-#pragma unroll
-    for (int t = 0; t < TW; ++t)
-#pragma unroll
-      for (int p = 0; p < PBW; ++p)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + q) * 64 + lane;
-          const u32x4 pv = a.Pprev[pidx];
-          u32x4 o;
-#pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2)
-            o[j2] = OP::pack2(acc[t][p][8 * q + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(pv[j2])),
-                              acc[t][p][8 * q + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(pv[j2])));
-          a.Out[pidx] = o;
-        }
-  } else {
+  // ---- epilogue: residual, SSE partial, dL/dout ----
+  {
     float sse = 0.f, d[3] = {0.f, 0.f, 0.f};
     if (h == 0 && valid) {
 #pragma unroll
