@@ -529,6 +529,9 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     fa.gscale = (float)((double)h->gpre / (3.0 * h->n_total));
     fa.pred = pred;
     fa.sse_part = h->sse_part + sse_off;
+#ifdef SF_EXPERIMENT_STAMP
+    fa.dbg = h->sse_part + h->n_sse;   // 64 spare floats behind the partials
+#endif
     sse_off += n_super;
     {
       Launch L(h, K_FWD, flops_fwd_px(h) * n_pb * 32.0,
@@ -721,7 +724,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
   { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4 + 4096); }
   h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
-  ALLOC(h->sse_part, h->n_sse * 4); ALLOC(h->sse_dev, 8);
+  ALLOC(h->sse_part, (h->n_sse + 64) * 4); ALLOC(h->sse_dev, 8);
 #undef ALLOC
   if (rc) { sf_destroy(h); return rc; }
   hipMemsetAsync(h->params, 0, h->P * 4, h->stream);
@@ -736,6 +739,13 @@ int sf_destroy(sf_handle* h) {
   if (!h) return SF_OK;
   if (h->stream || true) hipStreamSynchronize(h->stream);
 #ifdef SF_EXPERIMENT_STAMP
+  if (!h->wide) {
+    float dbg[16];
+    hipMemcpy(dbg, h->sse_part + h->n_sse, sizeof(dbg), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 4; ++i)
+      fprintf(stderr, "k_fwd stamp wg%d wave%d: hidden-layer loop %.0f cycles, barrier 1 (half X) %.0f, barrier 2 (half Y) %.0f, %d layers\n",
+              i >> 1 ? 9000 : 3, i & 1 ? 5 : 0, dbg[i * 4], dbg[i * 4 + 1], dbg[i * 4 + 2], (int)dbg[i * 4 + 3]);
+  }
   if (h->wide) {
     unsigned long long dbg[32];
     const size_t sw = 256;

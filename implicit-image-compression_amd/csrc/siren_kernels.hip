@@ -185,6 +185,7 @@ struct FwdArgs {
   float gscale;            // 1/(3*H*W): d(mse)/d(out) = (pred-img) * gscale   (the /2 of siren.py:131 folded in)
   float* pred;             // optional [npix][3]
   float* sse_part;         // [gridDim.x] per-workgroup sum of squared residuals
+  float* dbg;              // SF_EXPERIMENT_STAMP builds only
 };
 
 // Forward weight image of one hidden layer, as stored in HBM and copied verbatim into LDS:
@@ -294,13 +295,23 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
                            pack_phase2(ph[6], ph[7])});
     }
   };
+#ifdef SF_EXPERIMENT_STAMP
+  unsigned long long st_bar1 = 0, st_bar2 = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- hidden layers: [WD x WD] on MFMA, activations stay in registers ------------------------
   for (int l = 1; l <= a.depth - 2; ++l) {
     const u32x4* img_l = a.wf + (size_t)(l - 1) * IM::PIECES * 64;
     u32x4 Bn[KS];
     // half X of layer l landed (the epilogue stores issued after that DMA may stay in flight);
     // everyone left half Y of layer l-1
+#ifdef SF_EXPERIMENT_STAMP
+    unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
     if (l == 1) bar_dma<0>(); else bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>();
+#ifdef SF_EXPERIMENT_STAMP
+    { const unsigned long long t_b = __builtin_amdgcn_s_memtime(); st_bar1 += t_b - t_a; }
+#endif
     stage(img_l + IM::X_PIECES * 64, IM::X_PIECES, IM::Y_PIECES);
     asm volatile("" ::: "memory");
     f32x16 prev = tile_mma(0);
@@ -311,7 +322,13 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
       __builtin_amdgcn_sched_barrier(0);   // keep every epilogue next to its MFMA tile (no deferred sin blobs)
       prev = cur;
     }
+#ifdef SF_EXPERIMENT_STAMP
+    t_a = __builtin_amdgcn_s_memtime();
+#endif
     bar_dma<TRAIN ? 2 * (H0 - 1) : 0>();          // half Y landed; everyone left half X
+#ifdef SF_EXPERIMENT_STAMP
+    { const unsigned long long t_b = __builtin_amdgcn_s_memtime(); st_bar2 += t_b - t_a; }
+#endif
     if (l < a.depth - 2) stage(img_l + IM::PIECES * 64, 0, IM::X_PIECES);
     else stage(a.wf_last, 0, IM::LAST_PIECES);
     asm volatile("" ::: "memory");
@@ -327,6 +344,12 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
     for (int s = 0; s < KS; ++s) B[s] = Bn[s];
   }
 
+#ifdef SF_EXPERIMENT_STAMP
+  if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 9000)) {
+    float* o = a.dbg + ((blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 4;
+    o[0] = (float)(__builtin_amdgcn_s_memtime() - st_t0); o[1] = (float)st_bar1; o[2] = (float)st_bar2; o[3] = (float)(a.depth - 2);
+  }
+#endif
   // ---- last layer (out_features <= 3, padded to one 32-row tile) + residual ---------------------
   if (a.depth > 2) bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>(); else bar_dma<0>();
   f32x16 acc;
