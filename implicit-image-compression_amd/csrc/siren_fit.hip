@@ -698,6 +698,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   // not a power of two apart (HBM channel aliasing)
   h->p_stride = chunk / 32 * (WD / 16) * 64 + 37 * 64;
   h->dw_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("SIREN_FIT_BWD_WGS")) { const int v = atoi(e); if (v >= 8 && v <= h->dw_wg) h->dw_wg = v; }   // experiment knob
 
   auto alloc = [&](void** p, size_t bytes) -> int {
     hipError_t e = hipMalloc(p, bytes ? bytes : 16);
