@@ -258,6 +258,7 @@ int refresh_images(sf_engine* h) {
     a.off_b[l] = h->off_b[l];
   }
   a.wscale = h->wscale;
+  a.hscale = (float)((double)h->cfg.hidden_omega_0 / 6.283185307179586476925286766559);
   a.om_first = h->cfg.first_omega_0; a.om_hidden = h->cfg.hidden_omega_0;
   a.fwd_is_f16 = h->cfg.compute_dtype == SF_F16;
   a.wf = h->wf; a.wf_last = h->wf_last; a.wb = h->wb; a.wb_last = h->wb_last;
@@ -293,7 +294,8 @@ int refresh_images_wide(sf_engine* h) {
     t.params = h->params; t.depth = D; t.WD = WD; t.out_features = h->cfg.out_features;
     t.off_w0 = h->off_w[0]; t.off_b0 = h->off_b[0];
     for (int l = 0; l < D; ++l) t.off_b[l] = h->off_b[l];
-    t.wscale = h->wscale; t.l0tab = h->l0tab; t.bias = h->biasw;
+    t.wscale = h->wscale; t.hscale = (float)((double)h->cfg.hidden_omega_0 / 6.283185307179586476925286766559);
+    t.l0tab = h->l0tab; t.bias = h->biasw;
     long n = (long)(D - 2) * WD;
     if (n < WD) n = WD;
     hipLaunchKernelGGL(k_wtables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, t);
@@ -308,7 +310,8 @@ int refresh_images_wide(sf_engine* h) {
     hipLaunchKernelGGL(k_wimage, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
   };
   for (int l = 1; l <= D - 2; ++l) {
-    image(l, false, 8, NBLK, KS / 4, h->wscale, h->wf + (size_t)(l - 1) * WD * WD);
+    image(l, false, 8, NBLK, KS / 4, (float)((double)h->cfg.hidden_omega_0 / 6.283185307179586476925286766559),
+          h->wf + (size_t)(l - 1) * WD * WD);
     image(l, true, 8, NBLK, KS / 4, l - 1 == 0 ? h->cfg.first_omega_0 : h->cfg.hidden_omega_0, h->wb + (size_t)(l - 1) * WD * WD);
   }
   image(D - 1, false, 1, 1, KS / 4, h->wscale, h->wf_last);

@@ -174,7 +174,7 @@ struct FwdArgs {
   const u32x4* wf;         // (depth-2) forward images (FwdImg<WD>::PIECES pieces each, biases included)
   const u32x4* wf_last;    // forward image of the last layer padded to 32 rows + bias piece
   float sc_first;          // first_omega_0 / (2 pi)
-  float sc_hidden;         // hidden_omega_0 / (2 pi) / weight-image scale
+  float sc_hidden;         // unused since the hidden forward images carry omega/(2 pi): the accumulator IS the phase
   float sc_last;           // 1 / weight-image scale
   float last_om, last_om_rev;  // outermost_linear=False (siren.py:110-117): the last layer is sin(omega z) too;
                                // omega and omega/(2 pi), both 0 for the (default) linear last layer
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
       float av[8], ph[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float tt = acc[8 * q + j] * a.sc_hidden;
+        const float tt = acc[8 * q + j];   // revolutions: omega/(2 pi) is folded into the weight image and the bias
         av[j] = __builtin_amdgcn_sinf(tt);
         ph[j] = __builtin_amdgcn_fractf(tt);
       }
@@ -961,7 +961,10 @@ struct ImgArgs {
   const float* params;      // flat
   int depth, WD, out_features;
   long off_w[16], off_b[16];
-  float wscale;             // forward-image scale (power of two)
+  float wscale;             // scale of the LAST layer's forward image (power of two)
+  float hscale;             // scale of the hidden forward images and biases: hidden_omega_0 / (2 pi), so that the
+                            // MFMA accumulator of a hidden layer is the phase in revolutions (one VALU multiply
+                            // per output value less in the issue-bound k_fwd epilogue)
   float om_first, om_hidden; // backward images carry omega of layer l-1: d sin(om z)/dz = om cos(om z)
   int fwd_is_f16;
   uint16_t* wf; uint16_t* wf_last; uint16_t* wb; uint16_t* wb_last;
@@ -996,7 +999,7 @@ __global__ void k_images(ImgArgs a) {
     const int s = (int)(e % KS), tile = (int)(e / KS);
     const int r = lane & 31, h = lane >> 5;
     const float* Wl = a.params + a.off_w[l];
-    const float wfwd = Wl[(long)(32 * tile + r) * WD + 16 * s + pi_perm(h, j)] * a.wscale;
+    const float wfwd = Wl[(long)(32 * tile + r) * WD + 16 * s + pi_perm(h, j)] * a.hscale;
     const float wbwd = Wl[(long)(16 * s + pi_perm(h, j)) * WD + 32 * tile + r] * (l - 1 == 0 ? a.om_first : a.om_hidden);
     const long dst = ((long)(l - 1) * G.PIECES + G.tile_piece(tile) + s) * 512 + lane * 8 + j;
     a.wf[dst] = a.fwd_is_f16 ? to_f16(wfwd) : to_bf16(wfwd);
@@ -1005,7 +1008,7 @@ __global__ void k_images(ImgArgs a) {
   if (gid < (long)(a.depth - 2) * WD) {  // hidden biases into the bias pieces (fp32, pre-scaled)
     const int l = (int)(gid / WD) + 1, n = (int)(gid % WD), nt = n / 32;
     float* piece = reinterpret_cast<float*>(a.wf + ((long)(l - 1) * G.PIECES + G.bias_piece(nt)) * 512);
-    piece[G.bias_off(nt) + (n & 31)] = a.params[a.off_b[l] + n] * a.wscale;
+    piece[G.bias_off(nt) + (n & 31)] = a.params[a.off_b[l] + n] * a.hscale;
   }
   const int L = a.depth - 1;
   if (gid < (long)KS * 64 * 8) {  // last layer forward image: one tile of 32 padded rows

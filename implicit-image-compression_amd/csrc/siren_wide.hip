@@ -56,7 +56,7 @@ __global__ void k_wimage(WImgArgs a) {
 // layer-0 table {w00, w01, b0, 0} per neuron and the pre-scaled fp32 biases of the hidden layers 1..D-2
 // ([D-2][WD]) followed by the last layer's padded to 32
 struct WTabArgs {
-  const float* params; int depth, WD, out_features; long off_w0, off_b0; long off_b[16]; float wscale;
+  const float* params; int depth, WD, out_features; long off_w0, off_b0; long off_b[16]; float wscale, hscale;
   f32x4* l0tab; float* bias;
 };
 __global__ void k_wtables(WTabArgs a) {
@@ -68,7 +68,7 @@ __global__ void k_wtables(WTabArgs a) {
   const long nh = (long)(a.depth - 2) * a.WD;
   if (gid < nh) {
     const int l = (int)(gid / a.WD) + 1, n = (int)(gid % a.WD);
-    a.bias[gid] = a.params[a.off_b[l] + n] * a.wscale;
+    a.bias[gid] = a.params[a.off_b[l] + n] * a.hscale;
   }
   if (gid < 32) a.bias[nh + gid] = gid < a.out_features ? a.params[a.off_b[a.depth - 1] + gid] * a.wscale : 0.f;
 }
@@ -115,7 +115,7 @@ struct WGemmArgs {
   const u32x4* Bin;      // input tensor (F-layout, ks_in k-steps per pixel block): activations (MODE 0/1) or deltas (MODE 2)
   int ks_in;
   const float* bias;     // MODE 0/1: [out rows], pre-scaled; nullptr otherwise
-  float sc;              // MODE 0: omega/(2 pi)/wscale ; MODE 1: 1/wscale ; MODE 2: unused
+  float sc;              // MODE 1: 1/wscale ; unused otherwise (hidden images carry omega/(2 pi))
   u32x4* Out;            // MODE 0: phases out, MODE 2: deltas out (F-layout, ks_out k-steps per block)
   u32x4* OutAct;         // MODE 0: activations out (same geometry as Out)
   int ks_out;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
           float ph[8], av[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float tt = acc[t][p][8 * qq + j] * a.sc;
+            const float tt = acc[t][p][8 * qq + j];   // revolutions (scale folded into the image)
             ph[j] = __builtin_amdgcn_fractf(tt);
             av[j] = __builtin_amdgcn_sinf(tt);
           }

@@ -45,14 +45,13 @@ def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torc
     W0, b0 = params[0], params[1]
     z = torch.addcmul(torch.addcmul(b0, x[:, 0:1], W0[:, 0]), x[:, 1:2], W0[:, 1])   # fma order of k_fwd
     sc_first = torch.tensor(first_omega_0 / TWO_PI, dtype=torch.float32)
-    sc_hidden = torch.tensor(hidden_omega_0 / TWO_PI / ws, dtype=torch.float32)
+    hs = torch.tensor(hidden_omega_0 / TWO_PI, dtype=torch.float32)   # folded into the hidden forward images / biases
     t = z * sc_first
     ph0 = t - torch.floor(t)          # layer-0 phases are not spilled: k_bwd re-derives them from the coordinates
     q = [None]
     a = torch.sin(TWO_PI * t.double()).float()
     for l in range(1, depth - 1):
-        acc = _rt(a, fwd) @ _rt(params[2 * l] * ws, fwd).t() + params[2 * l + 1] * ws
-        t = acc * sc_hidden
+        t = _rt(a, fwd) @ _rt(params[2 * l] * hs, fwd).t() + params[2 * l + 1] * hs   # accumulator = phase (revolutions)
         q.append(_phase_q(t))
         a = torch.sin(TWO_PI * t.double()).float()
     L = depth - 1
