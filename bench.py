@@ -74,8 +74,8 @@ def cpu_baseline(hidden, depth, size, warm=1, timed=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)      # >= 20 timed, >= 5 warm-up steps
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--depth", type=int, default=8)
