@@ -767,7 +767,7 @@ int sf_destroy(sf_handle* h) {
                   h->sse_dev};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->gexec) hipGraphExecDestroy(h->gexec);
-  if (h->gstream) { hipStreamDestroy(h->gstream); hipEventDestroy(h->gev_in); hipEventDestroy(h->gev_out); }
+  if (h->gstream) { hipStreamSynchronize(h->gstream); hipStreamDestroy(h->gstream); hipEventDestroy(h->gev_in); hipEventDestroy(h->gev_out); }
   void* gptrs[] = {h->step_tab, h->loss_tab, h->iter_dev};
   for (void* p : gptrs) if (p) hipFree(p);
   delete h;
