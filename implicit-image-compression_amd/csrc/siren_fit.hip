@@ -338,8 +338,11 @@ int launch_wgemm(sf_engine* h, const WGemmArgs& a, int n_super, int n_ob) {
     const size_t lds = (size_t)4 * 32 * 1024;
     int rc = f16 ? set_lds(k_wgemm2<MODE, OpF16>, lds) : set_lds(k_wgemm2<MODE, OpBF16>, lds);
     if (rc) return rc;
-    if (f16) hipLaunchKernelGGL((k_wgemm2<MODE, OpF16>), dim3(grid), dim3(512), lds, h->stream, b);
-    else hipLaunchKernelGGL((k_wgemm2<MODE, OpBF16>), dim3(grid), dim3(512), lds, h->stream, b);
+    // persistent: one workgroup per CU (a multiple of 8 * n_ob, so XCD and output block are loop invariants)
+    unsigned pgrid = (unsigned)(h->dw_wg / (8 * n_ob) * (8 * n_ob));
+    if (pgrid == 0 || pgrid > grid) pgrid = grid;
+    if (f16) hipLaunchKernelGGL((k_wgemm2<MODE, OpF16>), dim3(pgrid), dim3(512), lds, h->stream, b);
+    else hipLaunchKernelGGL((k_wgemm2<MODE, OpBF16>), dim3(pgrid), dim3(512), lds, h->stream, b);
   }
   HIPCHK(hipGetLastError());
   return SF_OK;

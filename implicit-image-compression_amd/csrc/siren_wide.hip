@@ -262,21 +262,26 @@ template <int MODE, typename OP>
 __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
   static_assert(MODE == 0 || MODE == 2, "last layer: k_wgemm<1>");
   constexpr int OT = 8, TW = 4, PBW = 2, NB = 4, PD = 3, SLOT = 32 * 1024;
+  constexpr int NEP = MODE == 0 ? 2 * TW * PBW * 2 : TW * PBW * 2;   // epilogue stores per wave (phase + activation / delta)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int ob = q % a.n_ob;
-  const int sb = (q / a.n_ob) * 8 + xcd;
+  // PERSISTENT workgroups: gridDim.x is a multiple of 8 * n_ob, so along t = blockIdx.x + k * gridDim.x the XCD
+  // (t & 7) and the output block stay fixed and only the 256-pixel super-block advances.  The weight block
+  // and the bias are loop invariants; the first chunks of the NEXT tile are requested before the epilogue of
+  // the current one, so neither the DMA latency of a tile's prologue nor its store tail is exposed.
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int ob = q0 % a.n_ob;
+  const int sb_step = (gridDim.x >> 3) / a.n_ob * 8;
+  int sb = (q0 / a.n_ob) * 8 + xcd;
   if (sb >= a.n_super) return;
   const int t0 = TW * (wave & 1), pw = 2 * (wave >> 1);
-  const long pbg = (long)sb * kWavesFwd;                 // first pixel block of the workgroup
-  const long pb0 = pbg + pw;
   const u32x4* Ablk = a.A + (size_t)ob * a.a_block_pieces * 64;
   const int n2 = a.ks_in / 2;                            // chunks of 2 k-steps
-  auto stage = [&](int c) {
+  const bool pipe = n2 >= 4;                             // cross-tile prefetch (the K = 32 last-layer product: plain waits)
+  auto stage = [&](int tsb, int c) {
     char* base = smem + (c % NB) * SLOT;
-    // A piece (ot, s2) of chunk c lives at image piece ((c>>1)*OT + ot)*4 + 2*(c&1) + s2 ; B piece (p, s2)
+    const long pbg = (long)tsb * kWavesFwd;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pc = wave + 8 * i, ot = pc >> 1, s2 = pc & 1;
@@ -288,77 +293,113 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
       glds16s(a.Bin + ((pbg + p) * a.ks_in + 2 * c + s2) * 64, (uint32_t)lane * 16u, base + (16 + pc) * 1024);
     }
   };
-  f32x16 acc[TW][PBW];
+  f32x16 init[TW];
 #pragma unroll
   for (int t = 0; t < TW; ++t) {
-    f32x16 init = f32x16{};
+    init[t] = f32x16{};
     if (MODE == 0) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(&a.bias[(ob * OT + t0 + t) * 32 + 8 * q4 + 4 * h]);
-        init[4 * q4 + 0] = b.x; init[4 * q4 + 1] = b.y; init[4 * q4 + 2] = b.z; init[4 * q4 + 3] = b.w;
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < PBW; ++p) acc[t][p] = init;
-  }
-  asm volatile("" ::"v"(acc[0][0][0]));                  // bias loads retire before the first DMA is issued
-  for (int c = 0; c < PD && c < n2; ++c) stage(c);
-  for (int c = 0; c < n2; ++c) {
-    if (c + 2 < n2) bar_dma<8>(); else if (c + 1 < n2) bar_dma<4>(); else bar_all();
-    if (c + PD < n2) stage(c + PD);
-    asm volatile("" ::: "memory");
-    const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
-    const u32x4* sB = sA + 16 * 64;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      u32x4 b[PBW];
-#pragma unroll
-      for (int p = 0; p < PBW; ++p) b[p] = sB[((pw + p) * 2 + s2) * 64];
-#pragma unroll
-      for (int t = 0; t < TW; ++t) {
-        const u32x4 fa = sA[((t0 + t) * 2 + s2) * 64];
-#pragma unroll
-        for (int p = 0; p < PBW; ++p) acc[t][p] = OP::mfma(fa, b[p], acc[t][p]);
+        init[t][4 * q4 + 0] = b.x; init[t][4 * q4 + 1] = b.y; init[t][4 * q4 + 2] = b.z; init[t][4 * q4 + 3] = b.w;
       }
     }
   }
-  if (MODE == 0) {
+  asm volatile("" ::"v"(init[0][0]), "v"(init[TW - 1][15]));   // bias loads retire before the first DMA is issued
+  for (int c = 0; c < PD && c < n2; ++c) stage(sb, c);
+  bool first = true;
+  while (true) {
+    const long pb0 = (long)sb * kWavesFwd + pw;
+    f32x16 acc[TW][PBW];
 #pragma unroll
     for (int t = 0; t < TW; ++t)
 #pragma unroll
-      for (int p = 0; p < PBW; ++p)
+      for (int p = 0; p < PBW; ++p) acc[t][p] = init[t];
+    u32x4 pv[TW][PBW][2];                                  // MODE 2: phases for the cos factor, requested early
+    for (int c = 0; c < n2; ++c) {
+      // vmcnt is in-order: "chunk c landed" = all but the younger operations done; younger are the DMA of chunks
+      // c+1, c+2 and - in the first PD steps of a tile that follows another - that tile's NEP epilogue stores
+      if (!pipe) bar_all();
+      else if (c + 2 >= n2) { if (c + 1 < n2) bar_dma<4>(); else bar_all(); }
+      else if (first || c >= PD) bar_dma<8>();
+      else bar_dma<8 + NEP>();
+      if (c + PD < n2) stage(sb, c + PD);
+      asm volatile("" ::: "memory");
+      if (MODE == 2 && c == n2 - 1) {
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          float ph[8], av[8];
+        for (int t = 0; t < TW; ++t)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float tt = acc[t][p][8 * qq + j];   // revolutions (scale folded into the image)
-            ph[j] = __builtin_amdgcn_fractf(tt);
-            av[j] = __builtin_amdgcn_sinf(tt);
+          for (int p = 0; p < PBW; ++p)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+              pv[t][p][qq] = a.Pprev[((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane];
+      }
+      const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
+      const u32x4* sB = sA + 16 * 64;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4 b[PBW];
+#pragma unroll
+        for (int p = 0; p < PBW; ++p) b[p] = sB[((pw + p) * 2 + s2) * 64];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          const u32x4 fa = sA[((t0 + t) * 2 + s2) * 64];
+#pragma unroll
+          for (int p = 0; p < PBW; ++p) acc[t][p] = OP::mfma(fa, b[p], acc[t][p]);
+        }
+      }
+    }
+    const int sbn = sb + sb_step;
+    const bool more = sbn < a.n_super;
+    if (pipe && more) {
+      bar_lds();                                           // every wave is done reading this tile's last chunks
+      for (int c = 0; c < PD; ++c) stage(sbn, c);
+      asm volatile("" ::: "memory");
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int p = 0; p < PBW; ++p)
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            float ph[8], av[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float tt = acc[t][p][8 * qq + j];   // revolutions (scale folded into the image)
+              ph[j] = __builtin_amdgcn_fractf(tt);
+              av[j] = __builtin_amdgcn_sinf(tt);
+            }
+            const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane;
+            a.Out[pidx] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
+                                pack_phase2(ph[6], ph[7])};
+            a.OutAct[pidx] = u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]),
+                                   OP::pack2(av[6], av[7])};
           }
-          const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane;
-          a.Out[pidx] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
-                              pack_phase2(ph[6], ph[7])};
-          a.OutAct[pidx] = u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]),
-                                 OP::pack2(av[6], av[7])};
-        }
-  } else {
+    } else {
 #pragma unroll
-    for (int t = 0; t < TW; ++t)
+      for (int t = 0; t < TW; ++t)
 #pragma unroll
-      for (int p = 0; p < PBW; ++p)
+        for (int p = 0; p < PBW; ++p)
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane;
-          const u32x4 pv = a.Pprev[pidx];
-          u32x4 o;
+          for (int qq = 0; qq < 2; ++qq) {
+            const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane;
+            const u32x4 pvv = pv[t][p][qq];
+            u32x4 o;
 #pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2)
-            o[j2] = OP::pack2(acc[t][p][8 * qq + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(pv[j2])),
-                              acc[t][p][8 * qq + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(pv[j2])));
-          a.Out[pidx] = o;
-        }
+            for (int j2 = 0; j2 < 4; ++j2)
+              o[j2] = OP::pack2(acc[t][p][8 * qq + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(pvv[j2])),
+                                acc[t][p][8 * qq + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(pvv[j2])));
+            a.Out[pidx] = o;
+          }
+    }
+    if (!more) break;
+    if (!pipe) {
+      bar_lds();
+      for (int c = 0; c < PD && c < n2; ++c) stage(sbn, c);
+    }
+    sb = sbn;
+    first = false;
   }
 }
 
