@@ -850,6 +850,24 @@ int sf_set_coords(sf_handle* h, const float* rows, const float* cols) {
   if (!h || !rows || !cols) return fail(SF_ERR_INVALID, "null argument");
   HIPCHK(hipMemcpyAsync(h->gh, rows, (size_t)h->cfg.height * 4, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->gw, cols, (size_t)h->cfg.width * 4, hipMemcpyDeviceToDevice, h->stream));
+  // The forward indexes these vectors; the gradient kernels of layer 0 / layer 1 re-derive the coordinate of a
+  // pixel as i/(n-1) instead of loading it.  Both agree only for get_grid()'s linspace(0,1,n) (data.py:82-83):
+  // anything else is rejected here instead of training on inconsistent coordinates.
+  {
+    std::vector<float> hv((size_t)h->cfg.height + h->cfg.width);
+    HIPCHK(hipMemcpyAsync(hv.data(), h->gh, (size_t)h->cfg.height * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(hv.data() + h->cfg.height, h->gw, (size_t)h->cfg.width * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    auto is_linspace = [](const float* v, int n) {
+      for (int i = 0; i < n; ++i) {
+        const float ref = n > 1 ? (float)((double)i / (double)(n - 1)) : 0.f;
+        if (!(fabsf(v[i] - ref) <= 2e-6f)) return false;
+      }
+      return true;
+    };
+    if (!is_linspace(hv.data(), h->cfg.height) || !is_linspace(hv.data() + h->cfg.height, h->cfg.width))
+      return fail(SF_ERR_INVALID, "sf_set_coords: rows / cols must be torch.linspace(0, 1, n) (data.py:82-83)");
+  }
   h->have_coords = true;
   return SF_OK;
 }

@@ -99,7 +99,9 @@ int sf_state_ptr(sf_handle* h, int32_t which, float** dev_ptr);
 /* tell the engine that the caller wrote the parameters through the sf_state_ptr(…,0) view */
 int sf_params_changed(sf_handle* h);
 
-/* data: the two linspace vectors of get_grid (data.py:82-83) and the target image rows */
+/* data: the two linspace vectors of get_grid (data.py:82-83) and the target image rows.  rows / cols must be
+ * torch.linspace(0, 1, n) to within 2e-6 (the layer-0 gradient kernels re-derive coordinates as i/(n-1));
+ * anything else returns SF_ERR_INVALID */
 int sf_set_coords(sf_handle* h, const float* rows_dev /*[height]*/, const float* cols_dev /*[width]*/);
 int sf_set_target(sf_handle* h, const float* img_dev /*[(row_end-row_begin)*width*3], borrowed*/);
 

@@ -580,3 +580,15 @@ def test_wide_pixel_split_handles_compose():
         gs += part.get_grads()
     assert abs(tot - sse) <= 1e-6 * sse
     assert (gs - g).norm().item() <= 1e-5 * g.norm().item()
+
+
+def test_set_coords_rejects_non_linspace_vectors():
+    """the backward of layers 0/1 re-derives pixel coordinates as i/(n-1): vectors that are not get_grid()'s
+    linspace(0, 1, n) must be refused instead of silently training on inconsistent coordinates."""
+    from implicit_image._engine import SirenEngine
+    eng = SirenEngine(8, 12, 64, 3)
+    eng.set_coords(torch.linspace(0, 1, 8).cuda(), torch.linspace(0, 1, 12).cuda())
+    with pytest.raises(RuntimeError, match="linspace"):
+        eng.set_coords((torch.linspace(0, 1, 8) ** 2).cuda(), torch.linspace(0, 1, 12).cuda())
+    one = SirenEngine(1, 1, 64, 3)                       # a 1x1 grid: linspace(0, 1, 1) == [0]
+    one.set_coords(torch.zeros(1).cuda(), torch.zeros(1).cuda())
