@@ -592,3 +592,31 @@ def test_set_coords_rejects_non_linspace_vectors():
         eng.set_coords((torch.linspace(0, 1, 8) ** 2).cuda(), torch.linspace(0, 1, 12).cuda())
     one = SirenEngine(1, 1, 64, 3)                       # a 1x1 grid: linspace(0, 1, 1) == [0]
     one.set_coords(torch.zeros(1).cuda(), torch.zeros(1).cuda())
+
+
+def test_metric_size_shard_composition_and_determinism():
+    """BASELINE metric configuration at its FULL size (SIREN 256x8, 4096x4096x3, four 4 Mi-pixel chunks):
+    size-independent properties instead of an oracle run - two row-sharded handles (the pixel-split mode) add up
+    to the full-image SSE and gradient, and a second pass reproduces the first bit for bit."""
+    H = W = 4096
+    p = so.siren_init(256, 8, seed=0)
+    ys = torch.linspace(0, 1, H, device="cuda")[:, None, None]
+    xs = torch.linspace(0, 1, W, device="cuda")[None, :, None]
+    k = torch.tensor([1.0, 2.0, 3.0], device="cuda")
+    img = (0.5 + 0.25 * torch.sin(12 * xs * k) + 0.25 * torch.cos(9 * ys * k)).contiguous()
+    full = _engine(H, W, 256, 8, "f16", p)
+    full.set_target(img)
+    sse = full.forward_backward()
+    g = full.get_grads().clone()
+    assert math.isfinite(sse) and torch.isfinite(g).all()
+    assert full.forward_backward() == sse and torch.equal(full.get_grads(), g)
+    full.close()
+    tot, gs = 0.0, torch.zeros_like(g)
+    for r0, r1 in ((0, 2048), (2048, 4096)):
+        part = _engine(H, W, 256, 8, "f16", p, row_begin=r0, row_end=r1)
+        part.set_target(img[r0:r1].contiguous())
+        tot += part.forward_backward()
+        gs += part.get_grads()
+        part.close()
+    assert abs(tot - sse) <= 1e-6 * sse
+    assert (gs - g).norm().item() <= 1e-5 * g.norm().item()
