@@ -620,3 +620,30 @@ def test_metric_size_shard_composition_and_determinism():
         part.close()
     assert abs(tot - sse) <= 1e-6 * sse
     assert (gs - g).norm().item() <= 1e-5 * g.norm().item()
+
+
+def test_config5_shape_shard_composition_and_determinism():
+    """BASELINE config 5 network (SIREN 1024x12, wide kernels) on a 1024x1024 slice of its grid: the row-sharded
+    handles of the pixel-split mode add up to the full SSE / gradient; a second pass is bit-identical."""
+    H = W = 1024
+    p = so.siren_init(1024, 12, seed=0)
+    ys = torch.linspace(0, 1, H, device="cuda")[:, None, None]
+    xs = torch.linspace(0, 1, W, device="cuda")[None, :, None]
+    k = torch.tensor([1.0, 2.0, 3.0], device="cuda")
+    img = (0.5 + 0.25 * torch.sin(12 * xs * k) + 0.25 * torch.cos(9 * ys * k)).contiguous()
+    full = _engine(H, W, 1024, 12, "f16", p, chunk_pixels=1 << 19)      # two chunks
+    full.set_target(img)
+    sse = full.forward_backward()
+    g = full.get_grads().clone()
+    assert math.isfinite(sse) and torch.isfinite(g).all()
+    assert full.forward_backward() == sse and torch.equal(full.get_grads(), g)
+    full.close()
+    tot, gs = 0.0, torch.zeros_like(g)
+    for r0, r1 in ((0, 512), (512, 1024)):
+        part = _engine(H, W, 1024, 12, "f16", p, row_begin=r0, row_end=r1, chunk_pixels=1 << 19)
+        part.set_target(img[r0:r1].contiguous())
+        tot += part.forward_backward()
+        gs += part.get_grads()
+        part.close()
+    assert abs(tot - sse) <= 1e-6 * sse
+    assert (gs - g).norm().item() <= 1e-5 * g.norm().item()
