@@ -26,6 +26,42 @@ import torch  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak of MI355X (MI355X_MICROARCH.md chip table)
 
 
+KERNEL_SOURCES = ("siren_kernels.hip", "siren_wide.hip", "siren_fit.hip", "layout.h")
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources libsiren_fit.so is built from: a PMC traffic file is only valid for the
+    kernels it was measured on (scripts/pmc_traffic_json.py records the same hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "implicit-image-compression_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(kernel, args, npix):
+    """HBM bytes per launch of `kernel` from the newest committed PMC passes (profiles/r*_pmc_traffic*.json) taken
+    on EXACTLY these kernel sources and this launch geometry (one 4 Mi-pixel chunk of SIREN 256x8); otherwise
+    (None, reason) - a stale constant is worse than no number."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True)
+    if not files:
+        return None, "no profiles/r*_pmc_traffic*.json"
+    if not (args.hidden == 256 and args.depth == 8 and args.chunk == 0 and npix >= (1 << 22)):
+        return None, "PMC passes cover the default 256x8 / 4 Mi-pixel-chunk geometry only"
+    here = kernel_source_hash()
+    for f in files:
+        try:
+            pmc = json.load(open(f))
+        except Exception:
+            continue
+        if pmc.get("kernel_source_sha256") != here:
+            continue
+        if kernel in pmc.get("kernels", {}) and "hbm_bytes_per_launch" in pmc["kernels"][kernel]:
+            return pmc["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, "kernel sources changed since the committed PMC passes (kernel_source_sha256 mismatch)"
+
+
 def flops_per_pixel_iter(hidden, depth, out_features=3):
     """F = 6*P_w - 4*hidden, P_w = 2W + (D-2)W^2 + 3W (GEMM multiply-adds only)."""
     pw = 2 * hidden + (depth - 2) * hidden * hidden + out_features * hidden
@@ -81,6 +117,8 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--scratch", type=int, default=0, choices=[0, 8, 12, 16],
+                    help="sf_config.scratch_format: 0 = auto (12 at hidden <= 256: phase bytes + 16-bit deltas), 8 = phase bytes + fp8 deltas, 16 = round-1 format")
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -119,7 +157,7 @@ def main():
         from implicit_image.parallel import PixelSplitFit, shard_rows
         r0, r1 = shard_rows(H, world, rank)
     eng = SirenEngine(H, W, args.hidden, args.depth, compute_dtype=args.dtype, device=local_rank,
-                      chunk_pixels=args.chunk, row_begin=r0, row_end=r1)
+                      chunk_pixels=args.chunk, row_begin=r0, row_end=r1, scratch_format=args.scratch)
     # per-image sharding: every rank fits its own synthetic image (seed offset by rank), same init
     from implicit_image.models import Siren   # seed-0 SIREN init, random-init weights
     torch.manual_seed(0)
@@ -135,7 +173,7 @@ def main():
     def run_steps(n):
         if split:
             for _ in range(n):
-                psf.step(lr)
+                psf.step(lr, want_loss=False)
         else:
             eng.step([lr] * n)          # no host sync inside: losses stay on the device
 
@@ -172,15 +210,9 @@ def main():
         dom = max((k for k in kern if kern[k]["flops_per_launch"] > 0), key=lambda k: kern[k]["total_ms"])
         d = kern[dom]
         avg_ms = d["total_ms"] / d["launches"]
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (same launch geometry:
-        # one 4 Mi-pixel chunk of SIREN 256x8); null for any other configuration
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_chunk4M.json")))
-            if args.hidden == 256 and args.depth == 8 and args.chunk == 0 and H * W >= (1 << 22) and dom in pmc["kernels"]:
-                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected inside this process, so the
+        # value comes from the committed rocprofv3 --pmc passes - only if they were taken on these kernel sources
+        traffic, traffic_source = pmc_traffic(dom, args, eng.npix)
         ach = d["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
         out = {
             "metric": f"Mpixel-iters/s (fwd+bwd+Adam) @ SIREN-{args.hidden}x{args.depth}",
@@ -194,7 +226,7 @@ def main():
             "step_mfma_frac": value / world * 1e6 * F / (PEAK_BF16_TFLOPS * 1e12),   # per GPU
             "psnr_after_run": psnr,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": d["bytes_per_launch"],
                          "avg_launch_ms": avg_ms, "flops_per_launch": d["flops_per_launch"]},
             # the same kernel against the HBM roof (it moves 1.5 KiB per pixel per layer: delta and phase in,

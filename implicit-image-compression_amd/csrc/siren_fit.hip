@@ -6,6 +6,7 @@
 // The sequence mirrors one `train_epoch` of the reference (implicit_image/utils/train_helper.py:132-185)
 // for the full-batch grid (implicit_image/compress.py:137-138).
 #include "siren_kernels.hip"
+#include "siren_s8.hip"
 #include "siren_wide.hip"
 
 #include <math.h>
@@ -13,7 +14,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/siren_fit.h"
@@ -21,6 +25,18 @@
 using namespace sf;
 
 static thread_local std::string g_err;
+
+// sf_config carries the Adam betas as floats; torch.optim.Adam computes 1 - beta and beta^t on the Python double
+// (0.9, not 0.89999997615...).  The double meant is recovered as the shortest decimal that rounds to the float.
+static double shortest_double(float f) {
+  char buf[64];
+  for (int digits = 1; digits <= 9; ++digits) {
+    snprintf(buf, sizeof(buf), "%.*g", digits, (double)f);
+    const double d = strtod(buf, nullptr);
+    if ((float)d == f) return d;
+  }
+  return (double)f;
+}
 static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -32,6 +48,10 @@ static int fail(int code, const std::string& msg) {
       return fail(SF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
   } while (0)
 
+// 8-bit scratch: dL/dout is stored as residual * 2^10 in fp16 (residuals of 6e-8 .. 64 stay normal numbers); the
+// adaptive part of the gradient pre-scale is applied by k_bwd8<LAST> (siren_s8.hip)
+static constexpr float kResScale = 1024.0f;
+
 enum KernelId { K_FWD = 0, K_BWD_HIDDEN, K_BWD_LAST, K_DW_FIRST, K_REDUCE, K_SSE, K_ADAM, K_IMAGES, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_fwd",    "k_bwd_hidden", "k_bwd_last", "k_dw_first",
                                             "k_reduce", "k_sse",        "k_adam",     "k_images"};
@@ -39,6 +59,21 @@ static const char* kKernelNames[K_COUNT] = {"k_fwd",    "k_bwd_hidden", "k_bwd_l
 struct ProfRec {
   int id;
   hipEvent_t e0, e1;
+};
+
+// Every entry point runs with the handle's device current and restores the caller's device on return: a
+// process may drive engines on several GPUs, or change torch.cuda.current_device after sf_create.
+struct DevGuard {
+  int prev = -1, want = -1;
+  explicit DevGuard(int device) : want(device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != want) hipSetDevice(want);
+  }
+  ~DevGuard() {
+    if (prev >= 0 && prev != want) hipSetDevice(prev);
+  }
+  DevGuard(const DevGuard&) = delete;
+  DevGuard& operator=(const DevGuard&) = delete;
 };
 
 struct sf_engine {
@@ -53,6 +88,7 @@ struct sf_engine {
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *mask = nullptr;
   bool has_mask = false;
   int64_t step = 0;
+  double beta1_d = 0.9, beta2_d = 0.999;   // the Python doubles behind cfg.beta1/beta2 (shortest decimal that rounds to the float)
   // images
   uint16_t *wf = nullptr, *wf_last = nullptr, *wb = nullptr, *wb_last = nullptr;
   f32x4* l0tab = nullptr;
@@ -61,6 +97,10 @@ struct sf_engine {
   bool images_dirty = true;
   float wscale = 1.f;
   float gpre = 1.f;       // power-of-two pre-scale of dL/dout (fp16 backward operands), undone in k_reduce*
+  bool s8 = false;        // phase bytes (scratch_format 8 and 12): k_fwd<.., S8> + the kernels of siren_s8.hip
+  bool d8 = false;        // fp8 deltas under a per-chunk adaptive pre-scale (scratch_format 8)
+  long d_stride = 0;      // pieces per layer in the delta scratch (p_stride: phases)
+  float* scale_dev = nullptr;   // {gpre / n_values_total, 1 / gpre} as the kernels read them (adaptive when s8)
   // data
   float *gh = nullptr, *gw = nullptr;
   bool have_coords = false;
@@ -91,6 +131,7 @@ struct sf_engine {
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> ev_pool;   // recycled timing events (creating two per launch costs more than a small kernel)
   double prof_ms[K_COUNT] = {0};
   int64_t prof_n[K_COUNT] = {0};
   double prof_flops[K_COUNT] = {0}, prof_bytes[K_COUNT] = {0};
@@ -105,8 +146,12 @@ struct Launch {  // RAII-less helper: brackets a kernel launch with events when 
   Launch(sf_engine* h_, int id_, double flops, double bytes) : h(h_), id(id_) {
     if (h->prof) {
       r.id = id;
-      hipEventCreate(&r.e0);
-      hipEventCreate(&r.e1);
+      auto get = [&](hipEvent_t* e) {
+        if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); }
+        else hipEventCreate(e);
+      };
+      get(&r.e0);
+      get(&r.e1);
       hipEventRecord(r.e0, h->stream);
       h->prof_flops[id] += flops;   // totals; sf_profile_get reports the per-launch average
       h->prof_bytes[id] += bytes;
@@ -128,17 +173,27 @@ int prof_flush(sf_engine* h) {
     hipEventElapsedTime(&ms, r.e0, r.e1);
     h->prof_ms[r.id] += ms;
     h->prof_n[r.id] += 1;
-    hipEventDestroy(r.e0);
-    hipEventDestroy(r.e1);
+    h->ev_pool.push_back(r.e0);
+    h->ev_pool.push_back(r.e1);
   }
   h->recs.clear();
   return SF_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is set once per (device, kernel): the call costs microseconds and the
+// small fits are launch-latency bound (14 launches in 73 us at 64x4)
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)bytes));
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> done;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find({dev, fn});
+  if (it != done.end() && it->second >= bytes) return SF_OK;
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done[{dev, fn}] = bytes;
   return SF_OK;
 }
 
@@ -154,7 +209,11 @@ int launch_fwd_t(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
     if (rc) return rc;                                                   \
     hipLaunchKernelGGL((k_fwd<WD, OP, TR>), dim3(n_super), dim3(512), lds, h->stream, a); \
   } while (0)
-  if (f16) {
+  if (f16 && train && h->s8) {
+    int rc = set_lds(k_fwd<WD, OpF16, true, true>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_fwd<WD, OpF16, true, true>), dim3(n_super), dim3(512), lds, h->stream, a);
+  } else if (f16) {
     if (train) SF_FWD(OpF16, true); else SF_FWD(OpF16, false);
   } else {
     if (train) SF_FWD(OpBF16, true); else SF_FWD(OpBF16, false);
@@ -208,6 +267,86 @@ int launch_bwd(sf_engine* h, bool last, bool p0, const BwdLayerArgs& a, int n_wg
 #else
                 : launch_bwd_tp<256, 256, 2, 4, false, false, 5>(h, a, n_wg);
 #endif
+  }
+  return fail(SF_ERR_INVALID, "unsupported hidden width");
+}
+
+// 8-bit scratch path (siren_s8.hip): fp16 operands only
+template <int JW, int IW, int WR, int WC, bool LAST, bool P0, int NB, int PARK = 0, int NBP = 0, bool D8 = true>
+int launch_bwd8_k(sf_engine* h, const Bwd8Args& a, int n_wg) {
+  constexpr size_t lds = bwd8_lds_bytes<JW, IW, WR * WC, LAST, P0, NB, PARK, NBP, D8>();
+  static_assert(lds <= 160 * 1024, "k_bwd8 LDS budget");
+  int rc = set_lds(k_bwd8<JW, IW, WR, WC, LAST, P0, OpF16, NB, PARK, NBP, D8>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_bwd8<JW, IW, WR, WC, LAST, P0, OpF16, NB, PARK, NBP, D8>), dim3(n_wg), dim3(WR * WC * 64), lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+template <int JW, int IW, int WR, int WC, bool LAST, int NB, int NB0>
+int launch_bwd8_t(sf_engine* h, const Bwd8Args& a, int n_wg, bool p0) {
+  return p0 ? launch_bwd8_k<JW, IW, WR, WC, LAST, true, NB0>(h, a, n_wg) : launch_bwd8_k<JW, IW, WR, WC, LAST, false, NB>(h, a, n_wg);
+}
+// scratch_format 12: phase bytes, 16-bit float deltas (k_bwd8<.., D8 = false>).  Ring depths / parked W^T k-steps of the
+// 256-wide 8-wave forms are the combinations hipcc allocates WITHOUT a scratch reload inside the block loop (a reload's
+// vmcnt(0) also waits for every LDS-DMA in flight, i.e. it serialises the loop on HBM latency): DESIGN.md section 4.
+template <int JW, int IW, int WR, int WC, bool LAST, int NB>
+int launch_bwd12_t(sf_engine* h, const Bwd8Args& a, int n_wg, bool p0) {
+  return p0 ? launch_bwd8_k<JW, IW, WR, WC, LAST, true, NB, 0, 0, false>(h, a, n_wg)
+            : launch_bwd8_k<JW, IW, WR, WC, LAST, false, NB, 0, 0, false>(h, a, n_wg);
+}
+int launch_bwd12(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) {
+  switch (h->WD) {
+    case 32: return last ? launch_bwd12_t<32, 32, 1, 1, true, 8>(h, a, n_wg, p0) : launch_bwd12_t<32, 32, 1, 1, false, 8>(h, a, n_wg, p0);
+    case 64: return last ? launch_bwd12_t<32, 64, 1, 2, true, 8>(h, a, n_wg, p0) : launch_bwd12_t<64, 64, 2, 1, false, 8>(h, a, n_wg, p0);
+    case 128: return last ? launch_bwd12_t<32, 128, 1, 4, true, 8>(h, a, n_wg, p0) : launch_bwd12_t<128, 128, 2, 2, false, 8>(h, a, n_wg, p0);
+    case 256:
+      if (last) return launch_bwd12_t<32, 256, 1, 8, true, 8>(h, a, n_wg, p0);
+      // hidden: 5 delta slots (80 KiB) + 4 phase slots (32) + sines (32) + 2 parked k-steps (16) = 160 KiB
+      // layer 1 (P0, no phase ring): 5 delta slots + sines + 4 parked k-steps + layer-0 table = 148 KiB
+      return p0 ? launch_bwd8_k<256, 256, 2, 4, false, true, 5, 4, 0, false>(h, a, n_wg)
+                : launch_bwd8_k<256, 256, 2, 4, false, false, 5, 2, 4, false>(h, a, n_wg);
+  }
+  return fail(SF_ERR_INVALID, "unsupported hidden width");
+}
+int launch_bwd8(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) {
+  if (!h->d8) return launch_bwd12(h, last, p0, a, n_wg);
+  switch (h->WD) {
+    case 32: return last ? launch_bwd8_t<32, 32, 1, 1, true, 8, 8>(h, a, n_wg, p0) : launch_bwd8_t<32, 32, 1, 1, false, 8, 8>(h, a, n_wg, p0);
+    case 64: return last ? launch_bwd8_t<32, 64, 1, 2, true, 8, 8>(h, a, n_wg, p0) : launch_bwd8_t<64, 64, 2, 1, false, 8, 8>(h, a, n_wg, p0);
+    case 128: return last ? launch_bwd8_t<32, 128, 1, 4, true, 8, 8>(h, a, n_wg, p0) : launch_bwd8_t<128, 128, 2, 2, false, 8, 8>(h, a, n_wg, p0);
+    case 256:
+      // 8 waves (two per SIMD), W^T rows in registers; LDS: 5 + 5 ring slots of 8 KiB, 48 KiB fp16 deltas, 32 KiB fp16
+      // sines = 160 KiB; the P0 variant (no phase ring) takes 8 delta slots
+      if (last) return launch_bwd8_t<32, 256, 1, 8, true, 8, 8>(h, a, n_wg, p0);
+      {
+        static const int waves = [] { const char* e = getenv("SIREN_FIT_BWD8_WAVES"); return e ? atoi(e) : 4; }();   // experiment knob
+        if (waves == 8) return launch_bwd8_t<256, 256, 2, 4, false, 5, 8>(h, a, n_wg, p0);
+        if (waves == 83) return p0 ? launch_bwd8_k<256, 256, 2, 4, false, true, 4, 4>(h, a, n_wg)      // experiment: 8 waves,
+                                   : launch_bwd8_k<256, 256, 2, 4, false, false, 3, 4>(h, a, n_wg);   // 3-slot rings, 4 k-steps parked
+        if (waves == 81) return p0 ? launch_bwd8_k<256, 256, 2, 4, false, true, 6, 2>(h, a, n_wg)         // 8 waves, one / two k-steps of
+                                   : launch_bwd8_k<256, 256, 2, 4, false, false, 5, 1, 4>(h, a, n_wg);   // W^T parked behind a 4-slot phase ring
+        if (waves == 84) return p0 ? launch_bwd8_k<256, 256, 2, 4, false, true, 4, 4>(h, a, n_wg)
+                                   : launch_bwd8_k<256, 256, 2, 4, false, false, 4, 2>(h, a, n_wg);   // 4-slot rings, 2 k-steps parked
+        return launch_bwd8_t<256, 256, 2, 2, false, 5, 8>(h, a, n_wg, p0);
+      }
+  }
+  return fail(SF_ERR_INVALID, "unsupported hidden width");
+}
+template <int JW>
+int launch_dw0_8_t(sf_engine* h, const Dw0Args& a, int n_wg) {
+  const size_t lds = (size_t)(8 * (JW / 32) + 2 * (JW / 16)) * 1024 + 512;   // byte ring + two fp16 images + coordinate table
+  int rc = set_lds(k_dw0_8<JW, OpF16>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_dw0_8<JW, OpF16>), dim3(n_wg), dim3(JW * 2), lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+int launch_dw_first8(sf_engine* h, const Dw0Args& a, int n_wg) {
+  switch (h->WD) {
+    case 32: return launch_dw0_8_t<32>(h, a, n_wg);
+    case 64: return launch_dw0_8_t<64>(h, a, n_wg);
+    case 128: return launch_dw0_8_t<128>(h, a, n_wg);
+    case 256: return launch_dw0_8_t<256>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
@@ -397,7 +536,8 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       a.a_block_pieces = (long)KS; a.n_chunk = KS / 4;
       a.Bin = h->Abuf + (size_t)(D - 2) * h->p_stride; a.ks_in = KS;
       a.bias = h->biasw + (size_t)(D - 2) * WD; a.sc = 1.0f / h->wscale;
-      a.img = h->img; a.pred = pred; a.gscale = (float)((double)h->gpre / (3.0 * h->n_total));
+      a.img = h->img; a.pred = pred; a.nout = h->cfg.out_features;
+      a.gscale = (float)((double)h->gpre / ((double)h->cfg.out_features * h->n_total));
       a.sse_part = h->sse_part + sse_off; a.Dlast = train ? h->Dlast : nullptr; a.pix0 = pix0; a.npix = h->npix;
       if (!h->cfg.outermost_linear) { a.last_om = h->cfg.hidden_omega_0; a.last_om_rev = (float)((double)h->cfg.hidden_omega_0 / two_pi); }
       sse_off += n_super;
@@ -483,7 +623,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       }
       ReduceArgs ra;
       memset(&ra, 0, sizeof(ra));
-      ra.slab = h->slab; ra.n_wg = n_wg; ra.accumulate = c > 0; ra.scale = 1.0f / h->gpre;
+      ra.slab = h->slab; ra.n_wg = n_wg; ra.accumulate = c > 0; ra.scale = 1.0f / h->gpre; ra.scale_dev = nullptr;
       ra.gW = h->grads + h->off_w[0] + 512 * jb; ra.gb = h->grads + h->off_b[0] + 256 * jb;
       ra.slab_rows = 256; ra.slab_cols = 32; ra.rows_out = 256; ra.cols_out = 2; ra.mode = 1;
       const int n = 256 * 3;
@@ -532,7 +672,8 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     if (!h->cfg.outermost_linear) { fa.last_om = h->cfg.hidden_omega_0; fa.last_om_rev = (float)((double)h->cfg.hidden_omega_0 / two_pi); }
     fa.P = h->Pbuf; fa.p_stride = h->p_stride; fa.Dlast = h->Dlast;
     fa.img = h->img;
-    fa.gscale = (float)((double)h->gpre / (3.0 * h->n_total));
+    fa.nout = h->cfg.out_features;
+    fa.gscale = h->d8 ? kResScale : (float)((double)h->gpre / ((double)h->cfg.out_features * h->n_total));
     fa.pred = pred;
     fa.sse_part = h->sse_part + sse_off;
 #ifdef SF_EXPERIMENT_STAMP
@@ -541,7 +682,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     sse_off += n_super;
     {
       Launch L(h, K_FWD, flops_fwd_px(h) * n_pb * 32.0,
-               n_pb * 32.0 * (12.0 + (train ? (D - 2) * WD * 2.0 + 64.0 : 0.0)));
+               n_pb * 32.0 * (4.0 * h->cfg.out_features + (train ? (D - 2) * WD * (h->s8 ? 1.0 : 2.0) + (h->s8 ? 32.0 : 64.0) : 0.0)));
       rc = launch_fwd(h, fa, n_super, train);
       L.done();
       if (rc) return rc;
@@ -559,14 +700,45 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
       ReduceArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.slab = h->slab; ra.n_wg = n_wg; ra.accumulate = c > 0; ra.scale = 1.0f / h->gpre;
+      if (h->d8) {   // last layer: dW from the statically scaled residual; layers below: the chunk's adaptive pre-scale
+        ra.scale = (float)(1.0 / ((double)kResScale * (double)h->cfg.out_features * h->n_total));
+        ra.scale_dev = l == D - 1 ? nullptr : h->scale_dev;
+      }
       ra.gW = h->grads + h->off_w[l]; ra.gb = h->grads + h->off_b[l];
-      if (l > 0) {
+      if (l > 0 && h->s8) {
+        const bool last = l == D - 1, p0 = l - 1 == 0;
+        Bwd8Args ba;
+        memset(&ba, 0, sizeof(ba));
+        ba.D = last ? h->Dlast : h->Dbuf + (size_t)l * h->d_stride;
+        ba.P = h->Pbuf + (size_t)(l - 1) * h->p_stride;
+        ba.Dout = h->Dbuf + (size_t)(l - 1) * h->d_stride;
+        ba.wb = last ? reinterpret_cast<const u32x4*>(h->wb_last)
+                     : reinterpret_cast<const u32x4*>(h->wb) + (size_t)(l - 1) * img_pieces;
+        ba.n_pb = n_pb; ba.slab = h->slab;
+        ba.l0tab = h->l0tab; ba.pix0 = pix0; ba.npix = h->npix; ba.W = h->cfg.width; ba.row_begin = h->cfg.row_begin;
+        ba.w_magic = ((1ULL << 40) + (unsigned long long)h->cfg.width - 1) / (unsigned long long)h->cfg.width;
+        ba.inv_hm1 = h->cfg.height > 1 ? 1.0f / (float)(h->cfg.height - 1) : 0.f;
+        ba.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
+        ba.sc_first = fa.sc_first;
+        ba.sse_part = fa.sse_part; ba.n_part = n_super;
+        ba.inv_chunk_values = 1.0 / ((double)h->cfg.out_features * (double)px);
+        ba.n_values = (double)h->cfg.out_features * h->n_total;
+        ba.res_scale = kResScale; ba.target = 8.0f; ba.scale_out = h->scale_dev;
+        const double rows = last ? h->cfg.out_features : WD;
+        Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 4.0 * rows * WD * n_pb * 32.0,
+                 n_pb * 32.0 * ((last ? 32.0 : WD * (h->d8 ? 1.0 : 2.0)) + WD * (h->d8 ? 1.0 : 2.0) + (p0 ? 0.0 : WD * 1.0)));
+        rc = launch_bwd8(h, last, p0, ba, n_wg);
+        L.done();
+        if (rc) return rc;
+        ra.slab_rows = last ? 32 : WD; ra.slab_cols = WD;
+        ra.rows_out = last ? h->cfg.out_features : WD; ra.cols_out = WD; ra.mode = 0;
+      } else if (l > 0) {
         const bool last = l == D - 1;
         BwdLayerArgs ba;
         memset(&ba, 0, sizeof(ba));
-        ba.D = last ? h->Dlast : h->Dbuf + (size_t)l * h->p_stride;
+        ba.D = last ? h->Dlast : h->Dbuf + (size_t)l * h->d_stride;
         ba.P = h->Pbuf + (size_t)(l - 1) * h->p_stride;
-        ba.Dout = h->Dbuf + (size_t)(l - 1) * h->p_stride;
+        ba.Dout = h->Dbuf + (size_t)(l - 1) * h->d_stride;
         ba.wb = last ? reinterpret_cast<const u32x4*>(h->wb_last)
                      : reinterpret_cast<const u32x4*>(h->wb) + (size_t)(l - 1) * img_pieces;
         ba.n_pb = n_pb; ba.pb_per_wg = (int)pb_per_wg;
@@ -593,9 +765,9 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         da.inv_hm1 = h->cfg.height > 1 ? 1.0f / (float)(h->cfg.height - 1) : 0.f;
         da.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
         da.w_magic = ((1ULL << 40) + (unsigned long long)h->cfg.width - 1) / (unsigned long long)h->cfg.width;
-        Launch L(h, K_DW_FIRST, 4.0 * WD * n_pb * 32.0, WD * 2.0 * n_pb * 32.0);
+        Launch L(h, K_DW_FIRST, 4.0 * WD * n_pb * 32.0, WD * (h->d8 ? 1.0 : 2.0) * n_pb * 32.0);
         int n_wg0 = (int)(n_pb < (long)h->dw_wg ? n_pb : (long)h->dw_wg);
-        rc = launch_dw_first(h, da, n_wg0);
+        rc = h->d8 ? launch_dw_first8(h, da, n_wg0) : launch_dw_first(h, da, n_wg0);
         L.done();
         if (rc) return rc;
         ra.n_wg = n_wg0;
@@ -607,7 +779,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         if (l > 0 && l < D - 1) {   // slab layout == flat gradient layout [W | b]
           const int n4 = n / 4;
           hipLaunchKernelGGL(k_reduce_vec, dim3((n4 + 7) / 8), dim3(256), 0, h->stream, (const float*)h->slab,
-                             n_wg, (long)n, n4, h->grads + h->off_w[l], (int)ra.accumulate, ra.scale);
+                             n_wg, (long)n, n4, h->grads + h->off_w[l], (int)ra.accumulate, ra.scale, ra.scale_dev);
         } else {
           hipLaunchKernelGGL(k_reduce, dim3((n + 15) / 16), dim3(256), 0, h->stream, ra);
         }
@@ -654,13 +826,22 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   if (cfg->compute_dtype != SF_BF16 && cfg->compute_dtype != SF_F16)
     return fail(SF_ERR_INVALID, "compute_dtype must be SF_BF16 or SF_F16");
   if (cfg->height < 1 || cfg->width < 1) return fail(SF_ERR_INVALID, "bad image size");
+  if (cfg->scratch_format != 0 && cfg->scratch_format != 8 && cfg->scratch_format != 12 && cfg->scratch_format != 16)
+    return fail(SF_ERR_INVALID, "scratch_format must be 0 (auto), 8, 12 or 16");
+  if ((cfg->scratch_format == 8 || cfg->scratch_format == 12) && (cfg->hidden > 256 || cfg->compute_dtype != SF_F16))
+    return fail(SF_ERR_INVALID, "scratch_format 8 / 12 need hidden <= 256 and compute_dtype SF_F16");
   int r0 = cfg->row_begin, r1 = cfg->row_end;
   if (r0 == 0 && r1 == 0) r1 = cfg->height;
   if (r0 < 0 || r1 > cfg->height || r0 >= r1) return fail(SF_ERR_INVALID, "bad row range");
+  // the layer-0 / layer-1 gradient kernels decode (row, col) of a local pixel p as row = (p * ceil(2^40 / W)) >> 40,
+  // exact while p * W < 2^40, i.e. local_rows * W^2 < 2^40 (an unsharded 8192 x 8192 grid sits at 2^39)
+  if ((double)(r1 - r0) * (double)cfg->width * (double)cfg->width >= 1099511627776.0)
+    return fail(SF_ERR_INVALID, "grid too large for one handle: (row_end - row_begin) * width^2 must stay below 2^40 "
+                                "(shard the rows over more handles)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SF_ERR_NO_DEVICE, "no HIP device visible");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(SF_ERR_INVALID, "bad device ordinal");
-  HIPCHK(hipSetDevice(cfg->device));
+  DevGuard dev_guard(cfg->device);   // the caller's current device is restored on return
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -673,9 +854,18 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   if (h->cfg.beta1 == 0.f && h->cfg.beta2 == 0.f && h->cfg.eps == 0.f) {
     h->cfg.beta1 = 0.9f; h->cfg.beta2 = 0.999f; h->cfg.eps = 1e-8f;
   }
+  h->beta1_d = shortest_double(h->cfg.beta1);
+  h->beta2_d = shortest_double(h->cfg.beta2);
   h->D = cfg->depth;
   h->WD = cfg->hidden;
   h->wide = cfg->hidden > 256;
+  {
+    int fmt = cfg->scratch_format;
+    if (fmt == 0) fmt = (!h->wide && cfg->compute_dtype == SF_F16) ? 12 : 16;
+    h->cfg.scratch_format = fmt;
+    h->s8 = fmt == 8 || fmt == 12;
+    h->d8 = fmt == 8;
+  }
   h->stream = (hipStream_t)cfg->stream;
   h->npix = (long)(r1 - r0) * cfg->width;
   h->n_total = (double)cfg->height * (double)cfg->width;
@@ -691,7 +881,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   h->wscale = cfg->compute_dtype == SF_F16 ? 256.0f : 1.0f;
   // fp16 backward operands: dL/dout = resid/(3N) is pre-scaled by 2^k ~ 4*3N so the deltas sit around 1
   // (fp16 normal range 6e-5..65504); every gradient is multiplied back by 2^-k in the slab reduction
-  if (cfg->compute_dtype == SF_F16) h->gpre = (float)exp2(ceil(log2(3.0 * (double)cfg->height * (double)cfg->width)) + 2.0);
+  if (cfg->compute_dtype == SF_F16) h->gpre = (float)exp2(ceil(log2((double)cfg->out_features * (double)cfg->height * (double)cfg->width)) + 2.0);
   // chunking
   // default: 4 Mi pixels at width <= 256 (29 GB of scratch at 256x8); the same scratch budget for wider layers
   long chunk = cfg->chunk_pixels > 0 ? cfg->chunk_pixels : (1L << 22) / (h->wide ? cfg->hidden / 256 : 1);
@@ -702,7 +892,10 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   const int WD = h->WD, D = h->D;
   // layer stride of the scratch tensors, padded so that the three streams a kernel touches at once are
   // not a power of two apart (HBM channel aliasing)
-  h->p_stride = chunk / 32 * (WD / 16) * 64 + 37 * 64;
+  // (8-bit scratch: one piece per 32-neuron tile instead of one per 16-neuron k-step)
+  h->p_stride = chunk / 32 * (h->s8 ? WD / 32 : WD / 16) * 64 + 37 * 64;
+  h->d_stride = chunk / 32 * (h->d8 ? WD / 32 : WD / 16) * 64 + 37 * 64;
+
   h->dw_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("SIREN_FIT_BWD_WGS")) { const int v = atoi(e); if (v >= 8 && v <= h->dw_wg) h->dw_wg = v; }   // experiment knob
 
@@ -726,14 +919,21 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   }
   ALLOC(h->l0tab, (size_t)WD * 16);
   ALLOC(h->gh, (size_t)cfg->height * 4); ALLOC(h->gw, (size_t)cfg->width * 4);
-  ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->p_stride * 16);
+  ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->d_stride * 16);
   if (h->wide) ALLOC(h->Abuf, (size_t)(D - 1) * h->p_stride * 16);
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
   { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4 + 4096); }
   h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
-  ALLOC(h->sse_part, (h->n_sse + 64) * 4); ALLOC(h->sse_dev, 8);
+  ALLOC(h->sse_part, (h->n_sse + 64) * 4); ALLOC(h->sse_dev, 8); ALLOC(h->scale_dev, 16);
 #undef ALLOC
   if (rc) { sf_destroy(h); return rc; }
+  {
+    const float sc[2] = {(float)((double)h->gpre / ((double)cfg->out_features * h->n_total)), 1.0f / h->gpre};
+    if (hipMemcpy(h->scale_dev, sc, sizeof(sc), hipMemcpyHostToDevice) != hipSuccess) {
+      sf_destroy(h);
+      return fail(SF_ERR_HIP, "hipMemcpy(scale) failed");
+    }
+  }
   hipMemsetAsync(h->params, 0, h->P * 4, h->stream);
   hipMemsetAsync(h->grads, 0, h->P * 4, h->stream);
   hipMemsetAsync(h->m, 0, h->P * 4, h->stream);
@@ -744,6 +944,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
 
 int sf_destroy(sf_handle* h) {
   if (!h) return SF_OK;
+  DevGuard dev_guard(h->cfg.device);
   if (h->stream || true) hipStreamSynchronize(h->stream);
 #ifdef SF_EXPERIMENT_STAMP
   if (!h->wide) {
@@ -765,9 +966,10 @@ int sf_destroy(sf_handle* h) {
   }
 #endif
   for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab,
                   h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part, h->biasw, h->Abuf,
-                  h->sse_dev};
+                  h->sse_dev, h->scale_dev};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->gexec) hipGraphExecDestroy(h->gexec);
   if (h->gstream) { hipStreamSynchronize(h->gstream); hipStreamDestroy(h->gstream); hipEventDestroy(h->gev_in); hipEventDestroy(h->gev_out); }
@@ -791,11 +993,13 @@ int sf_param_offset(const sf_handle* h, int32_t layer, int64_t* w, int64_t* b) {
 
 static int copy_in(sf_engine* h, float* dst, const float* src) {
   if (!h || !src) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   HIPCHK(hipMemcpyAsync(dst, src, h->P * 4, hipMemcpyDeviceToDevice, h->stream));
   return SF_OK;
 }
 static int copy_out(sf_engine* h, float* dst, const float* src) {
   if (!h || !dst) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   HIPCHK(hipMemcpyAsync(dst, src, h->P * 4, hipMemcpyDeviceToDevice, h->stream));
   return SF_OK;
 }
@@ -809,6 +1013,7 @@ int sf_get_grads(sf_handle* h, float* p) { return copy_out(h, p, h ? h->grads : 
 int sf_set_grads(sf_handle* h, const float* p) { return copy_in(h, h ? h->grads : nullptr, p); }
 int sf_set_masks(sf_handle* h, const float* p) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   if (!p) { h->has_mask = false; return SF_OK; }
   int rc = copy_in(h, h->mask, p);
   if (!rc) h->has_mask = true;
@@ -816,6 +1021,7 @@ int sf_set_masks(sf_handle* h, const float* p) {
 }
 int sf_get_adam_state(sf_handle* h, float* m, float* v, int64_t* step) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   if (m) { int rc = copy_out(h, m, h->m); if (rc) return rc; }
   if (v) { int rc = copy_out(h, v, h->v); if (rc) return rc; }
   if (step) *step = h->step;
@@ -823,6 +1029,7 @@ int sf_get_adam_state(sf_handle* h, float* m, float* v, int64_t* step) {
 }
 int sf_set_adam_state(sf_handle* h, const float* m, const float* v, int64_t step) {
   if (!h || step < 0) return fail(SF_ERR_INVALID, "bad argument");
+  DevGuard dev_guard(h->cfg.device);
   if (m) { int rc = copy_in(h, h->m, m); if (rc) return rc; }
   if (v) { int rc = copy_in(h, h->v, v); if (rc) return rc; }
   h->step = step;
@@ -840,6 +1047,24 @@ int sf_state_ptr(sf_handle* h, int32_t which, float** p) {
   return fail(SF_ERR_INVALID, "bad state selector");
 }
 
+int sf_sse_ptr(sf_handle* h, double** p) {
+  if (!h || !p) return fail(SF_ERR_INVALID, "null argument");
+  *p = h->sse_dev;
+  return SF_OK;
+}
+
+int sf_debug_scratch(sf_handle* h, int32_t which, void** p, int64_t* bytes) {
+  if (!h || !p || !bytes) return fail(SF_ERR_INVALID, "null argument");
+  const int D = h->D;
+  switch (which) {
+    case 0: *p = h->Pbuf; *bytes = (int64_t)(D - 1) * h->p_stride * 16; return SF_OK;
+    case 1: *p = h->Dbuf; *bytes = (int64_t)(D - 1) * h->d_stride * 16; return SF_OK;
+    case 2: *p = h->Dlast; *bytes = (int64_t)(h->chunk_px / 32) * (h->s8 ? 1 : 2) * 64 * 16; return SF_OK;
+    case 3: { const size_t sw = h->WD > 256 ? 256 : h->WD; *p = h->slab; *bytes = (int64_t)h->dw_wg * (sw * sw + sw) * 4; return SF_OK; }
+  }
+  return fail(SF_ERR_INVALID, "bad scratch selector");
+}
+
 int sf_params_changed(sf_handle* h) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   h->images_dirty = true;
@@ -848,6 +1073,7 @@ int sf_params_changed(sf_handle* h) {
 
 int sf_set_coords(sf_handle* h, const float* rows, const float* cols) {
   if (!h || !rows || !cols) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   HIPCHK(hipMemcpyAsync(h->gh, rows, (size_t)h->cfg.height * 4, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->gw, cols, (size_t)h->cfg.width * 4, hipMemcpyDeviceToDevice, h->stream));
   // The forward indexes these vectors; the gradient kernels of layer 0 / layer 1 re-derive the coordinate of a
@@ -879,6 +1105,7 @@ int sf_set_target(sf_handle* h, const float* img) {
 
 int sf_forward(sf_handle* h, float* pred, double* sse_out) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   const bool want = sse_out != nullptr;
   const float* keep = h->img;
   int rc = run_pass(h, false, pred, want);
@@ -890,6 +1117,7 @@ int sf_forward(sf_handle* h, float* pred, double* sse_out) {
 
 int sf_forward_backward(sf_handle* h, double* sse_out) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   int rc = run_pass(h, true, nullptr, true);
   if (rc) return rc;
   if (sse_out) return read_sse(h, sse_out);
@@ -898,6 +1126,7 @@ int sf_forward_backward(sf_handle* h, double* sse_out) {
 
 int sf_adam_step(sf_handle* h, float lr) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   h->step += 1;
   AdamArgs a;
   memset(&a, 0, sizeof(a));
@@ -905,8 +1134,11 @@ int sf_adam_step(sf_handle* h, float lr) {
   a.p = h->params; a.g = h->grads; a.m = h->m; a.v = h->v; a.mask = h->has_mask ? h->mask : nullptr;
   a.n = h->P;
   a.beta1 = h->cfg.beta1; a.beta2 = h->cfg.beta2; a.eps = h->cfg.eps;
-  const double bc1 = 1.0 - pow((double)h->cfg.beta1, (double)h->step);
-  const double bc2 = 1.0 - pow((double)h->cfg.beta2, (double)h->step);
+  // torch forms 1 - beta in double and hands the kernel the rounded float (0.1f, 0.001f); 1.0f - beta in fp32 is
+  // 0.100000024 / 0.000999987
+  a.omb1 = (float)(1.0 - h->beta1_d); a.omb2 = (float)(1.0 - h->beta2_d);
+  const double bc1 = 1.0 - pow(h->beta1_d, (double)h->step);
+  const double bc2 = 1.0 - pow(h->beta2_d, (double)h->step);
   a.step_size = (float)((double)lr / bc1);
   a.bc2_sqrt = (float)sqrt(bc2);
   Launch L(h, K_ADAM, 0, (double)h->P * 28);
@@ -948,7 +1180,7 @@ static int step_replay(sf_engine* h, const float* lr, int n, float* loss_out) {
   std::vector<float> tab((size_t)n * 2);
   for (int i = 0; i < n; ++i) {
     const double t = (double)(h->step + i + 1);
-    const double bc1 = 1.0 - pow((double)h->cfg.beta1, t), bc2 = 1.0 - pow((double)h->cfg.beta2, t);
+    const double bc1 = 1.0 - pow(h->beta1_d, t), bc2 = 1.0 - pow(h->beta2_d, t);
     tab[2 * i] = (float)((double)lr[i] / bc1);
     tab[2 * i + 1] = (float)sqrt(bc2);
   }
@@ -988,7 +1220,7 @@ static int step_replay(sf_engine* h, const float* lr, int n, float* loss_out) {
     std::vector<double> sse((size_t)n);
     HIPCHK(hipMemcpyAsync(sse.data(), h->loss_tab, (size_t)n * 8, hipMemcpyDeviceToHost, h->gstream));
     HIPCHK(hipStreamSynchronize(h->gstream));
-    for (int i = 0; i < n; ++i) loss_out[i] = (float)(sse[i] / (3.0 * (double)h->npix));
+    for (int i = 0; i < n; ++i) loss_out[i] = (float)(sse[i] / ((double)h->cfg.out_features * (double)h->npix));
   }
   HIPCHK(hipEventRecord(h->gev_out, h->gstream));
   HIPCHK(hipStreamWaitEvent(user, h->gev_out, 0));
@@ -997,6 +1229,7 @@ static int step_replay(sf_engine* h, const float* lr, int n, float* loss_out) {
 
 int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) {
   if (!h || !lr || n_steps < 0) return fail(SF_ERR_INVALID, "bad argument");
+  DevGuard dev_guard(h->cfg.device);
   if (!h->have_coords) return fail(SF_ERR_STATE, "sf_set_coords has not been called");
   if (!h->img) return fail(SF_ERR_STATE, "sf_set_target has not been called");
   if (h->want_replay && n_steps >= 2 && !h->prof && h->npix <= h->chunk_px) return step_replay(h, lr, n_steps, loss_out);
@@ -1014,7 +1247,7 @@ int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) {
     std::vector<double> sse((size_t)n_steps);
     HIPCHK(hipMemcpyAsync(sse.data(), h->loss_tab, (size_t)n_steps * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n_steps; ++i) loss_out[i] = (float)(sse[i] / (3.0 * (double)h->npix));
+    for (int i = 0; i < n_steps; ++i) loss_out[i] = (float)(sse[i] / ((double)h->cfg.out_features * (double)h->npix));
     return SF_OK;
   }
   for (int i = 0; i < n_steps; ++i) {
@@ -1024,7 +1257,7 @@ int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) {
       double sse = 0;
       rc = read_sse(h, &sse);
       if (rc) return rc;
-      loss_out[i] = (float)(sse / (3.0 * (double)h->npix));
+      loss_out[i] = (float)(sse / ((double)h->cfg.out_features * (double)h->npix));
     }
     rc = sf_adam_step(h, lr[i]);
     if (rc) return rc;
@@ -1040,12 +1273,14 @@ int sf_set_graph_replay(sf_handle* h, int32_t on) {
 
 int sf_profile_enable(sf_handle* h, int32_t on) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   if (!on) { int rc = prof_flush(h); if (rc) return rc; }
   h->prof = on != 0;
   return SF_OK;
 }
 int sf_profile_reset(sf_handle* h) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
+  DevGuard dev_guard(h->cfg.device);
   int rc = prof_flush(h);
   if (rc) return rc;
   for (int i = 0; i < K_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; h->prof_flops[i] = 0; h->prof_bytes[i] = 0; }
@@ -1059,6 +1294,7 @@ int sf_profile_num_kernels(const sf_handle* h, int32_t* n) {
 int sf_profile_get(sf_handle* h, int32_t idx, const char** name, double* total_ms, int64_t* launches,
                    double* flops_per_launch, double* bytes_per_launch) {
   if (!h || idx < 0 || idx >= K_COUNT) return fail(SF_ERR_INVALID, "bad kernel index");
+  DevGuard dev_guard(h->cfg.device);
   int rc = prof_flush(h);
   if (rc) return rc;
   if (name) *name = kKernelNames[idx];

@@ -95,6 +95,56 @@ DEV float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u
 
 constexpr float kInv65535 = 1.0f / 65535.0f;
 
+// ---- 8-bit scratch formats (sf_config.scratch_format = 8) ------------------------------------------------------
+// Phase byte: u = round(t * 256) mod 256 for a phase t in revolutions, decoded as u / 256 rev (|d sin| <= 1.3e-2,
+// zero-mean over the pixels a gradient sums over).  t + 1.5 * 2^15 has ulp 2^-8, so the low mantissa byte of the
+// sum IS u (two's complement wrap covers negative t); v_add_f32_sdwa writes that byte straight into byte n of the
+// destination and preserves the other three: ONE instruction per value (verified on gfx950:
+// scripts/probes/isa_probe.hip).  |t| must stay below 2^14 revolutions.
+constexpr float kPhaseMagic = 49152.0f;
+// `after` is a value the compiler itself computed FROM t (here sin(t)): it is not used by the instruction, it only
+// orders it.  hipcc's hazard recognizer pads the MFMA-result -> VALU-read wait states for instructions it knows, not
+// for the operands of an asm statement; if this add were the first reader of a fresh accumulator it would read
+// it while the matrix pipe is still writing (seen as run-to-run different phase bytes in k_fwd<256> only).
+template <int BYTE>
+DEV void phase_byte(uint32_t& dst, float t, float after) {
+  static_assert(BYTE >= 0 && BYTE < 4, "byte lane");
+  // byte 0 is written first and pads the rest of the register with zeros (no dependence on an initial value)
+  if constexpr (BYTE == 0) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(dst) : "v"(t), "v"(kPhaseMagic), "v"(after));
+  if constexpr (BYTE == 1) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(t), "v"(kPhaseMagic), "v"(after));
+  if constexpr (BYTE == 2) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(t), "v"(kPhaseMagic), "v"(after));
+  if constexpr (BYTE == 3) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(t), "v"(kPhaseMagic), "v"(after));
+}
+DEV uint32_t phase_byte4(const float* t, const float* after) {
+  uint32_t r;
+  phase_byte<0>(r, t[0], after[0]); phase_byte<1>(r, t[1], after[1]); phase_byte<2>(r, t[2], after[2]); phase_byte<3>(r, t[3], after[3]);
+  return r;
+}
+// decode of byte n: u / 256 revolutions (v_cvt_f32_ubyteN + one multiply)
+template <int BYTE>
+DEV float phase_rev8(uint32_t p) { return (float)((p >> (8 * BYTE)) & 0xffu) * (1.0f / 256.0f); }
+
+// Delta byte: OCP fp8 e4m3 (3-bit significand, 2^-9 .. 448), SATURATING (the plain conversion returns NaN beyond
+// +-448: isa_probe).  Deltas carry one power-of-two scale per pixel chunk, derived by k_bwd8<LAST> from the chunk's
+// own residual so that rms(dL/dout) lands in (4, 8]: e4m3's range then sits around the data at every stage of a fit,
+// and the consumer's fp8 -> fp16 conversion needs no scale at all (e4m3's range is inside fp16's).
+// (min/max with literals, not v_med3_f32: a VOP3 instruction cannot take a literal, and the two bounds would each
+//  occupy a register for the whole kernel)
+DEV float sat448(float x) { return __builtin_fmaxf(__builtin_fminf(x, 448.0f), -448.0f); }
+DEV uint32_t fp8x4_sat(float a, float b, float c, float d) {
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(a), sat448(b), 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(c), sat448(d), r, true);
+  return (uint32_t)r;
+}
+// 8 fp8 (two dwords) -> 8 fp16 (one B-operand / piece element of 16 bytes)
+DEV u32x4 fp8x8_to_f16(uint32_t lo, uint32_t hi) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(lo, 1.0f, true);
+  const h2 c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(hi, 1.0f, true);
+  return u32x4{__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, c),
+               __builtin_bit_cast(uint32_t, d)};
+}
+
 // Phase decode for v_sin_f32 / v_cos_f32 (which take REVOLUTIONS and are 1-periodic): the unorm16 phase u
 // is dropped into the mantissa of a float in [1,2): x = 1 + u/65536 (+ <2^-16 from the neighbour's bits in
 // the high-half form).  Two integer ops per value instead of and/shift + cvt + mul; the 65535-vs-65536
@@ -178,12 +228,18 @@ struct FwdArgs {
   float sc_last;           // 1 / weight-image scale
   float last_om, last_om_rev;  // outermost_linear=False (siren.py:110-117): the last layer is sin(omega z) too;
                                // omega and omega/(2 pi), both 0 for the (default) linear last layer
-  u32x4* P;                // phases, layer l at P + l*p_stride, F-layout
+  u32x4* P;                // phases, layer l at P + l*p_stride.  16-bit scratch: unorm16, F-layout (KS pieces per
+                           // pixel block); 8-bit scratch: phase bytes, one piece per (pixel block, 32-neuron tile):
+                           // byte 8q+j of lane (h,m) = neuron 32*nt + 16*q + PI(h,j)  (NT pieces per pixel block)
   long p_stride;           // pieces per layer in the scratch
-  u32x4* Dlast;            // delta of the last layer, F-layout with 2 k-steps (32 padded neurons), bf16
-  const float* img;        // [npix][3] target
-  float gscale;            // 1/(3*H*W): d(mse)/d(out) = (pred-img) * gscale   (the /2 of siren.py:131 folded in)
-  float* pred;             // optional [npix][3]
+  u32x4* Dlast;            // dL/dout, F-layout, 16-bit float: 2 k-steps per block (16-bit scratch; the second is zero)
+                           // or 1 k-step per block (8-bit scratch: k_bwd8 keeps the zero k-step in LDS)
+  // (8-bit scratch: gscale is the STATIC 2^10 the residual is stored with; k_bwd8<LAST> applies the chunk's
+  //  adaptive factor when it forms the first hidden delta)
+  const float* img;        // [npix][nout] target
+  int nout;                // out_features (1..3): channel count and stride of img / pred
+  float gscale;            // 1/(nout*H*W): d(mse)/d(out) = (pred-img) * gscale   (the /2 of siren.py:131 folded in)
+  float* pred;             // optional [npix][nout]
   float* sse_part;         // [gridDim.x] per-workgroup sum of squared residuals
   float* dbg;              // SF_EXPERIMENT_STAMP builds only
 };
@@ -205,10 +261,11 @@ struct FwdImg {
   static __host__ __device__ constexpr int bias_off(int nt) { return (nt < H0 ? nt : nt - H0) * 32; }
 };
 
-template <int WD, typename OP, bool TRAIN>
+template <int WD, typename OP, bool TRAIN, bool S8 = false>
 __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   using IM = FwdImg<WD>;
   constexpr int NT = IM::NT, KS = IM::KS, H0 = IM::H0;
+  constexpr int SPT = S8 ? 1 : 2;   // phase stores per tile epilogue (what the counted vmcnt waits leave in flight)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u32x4* sW = reinterpret_cast<u32x4*>(smem);                                  // IM::PIECES pieces
   f32x4* sL0 = reinterpret_cast<f32x4*>(smem + (size_t)IM::PIECES * 1024);     // WD
@@ -232,7 +289,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   float tgt[3] = {0.f, 0.f, 0.f};
   if (a.img && h == 0 && valid) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) tgt[c] = a.img[pix * 3 + c];
+    for (int c = 0; c < 3; ++c) if (c < a.nout) tgt[c] = a.img[pix * a.nout + c];
   }
   // the ordinary loads above are consumed before the first DMA is issued, so the compiler's
   // vmcnt(0) for them does not drain the weight prefetch
@@ -278,6 +335,26 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
     return acc;
   };
   auto tile_epi = [&](const f32x16& acc, int nt, int l, u32x4* Bn) {
+    if constexpr (S8) {   // 8-bit scratch: one 16-byte phase piece element per tile (both k-steps), 1 VALU per byte
+      u32x4 pb8;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float av[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) av[j] = __builtin_amdgcn_sinf(acc[8 * q + j]);
+        Bn[2 * nt + q] =
+            u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]), OP::pack2(av[6], av[7])};
+        if (TRAIN) {
+          float tv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) tv[j] = acc[8 * q + j];
+          pb8[2 * q] = phase_byte4(tv, av);
+          pb8[2 * q + 1] = phase_byte4(tv + 4, av + 4);
+        }
+      }
+      if (TRAIN) store_stream(&a.P[(size_t)l * a.p_stride + (pb * NT + nt) * 64 + lane], pb8);
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float av[8], ph[8];
@@ -308,7 +385,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
 #ifdef SF_EXPERIMENT_STAMP
     unsigned long long t_a = __builtin_amdgcn_s_memtime();
 #endif
-    if (l == 1) bar_dma<0>(); else bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>();
+    if (l == 1) bar_dma<0>(); else bar_dma<TRAIN ? SPT * (IM::H1 + 1) : 0>();
 #ifdef SF_EXPERIMENT_STAMP
     { const unsigned long long t_b = __builtin_amdgcn_s_memtime(); st_bar1 += t_b - t_a; }
 #endif
@@ -325,7 +402,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
 #ifdef SF_EXPERIMENT_STAMP
     t_a = __builtin_amdgcn_s_memtime();
 #endif
-    bar_dma<TRAIN ? 2 * (H0 - 1) : 0>();          // half Y landed; everyone left half X
+    bar_dma<TRAIN ? SPT * (H0 - 1) : 0>();          // half Y landed; everyone left half X
 #ifdef SF_EXPERIMENT_STAMP
     { const unsigned long long t_b = __builtin_amdgcn_s_memtime(); st_bar2 += t_b - t_a; }
 #endif
@@ -351,7 +428,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
   }
 #endif
   // ---- last layer (out_features <= 3, padded to one 32-row tile) + residual ---------------------
-  if (a.depth > 2) bar_dma<TRAIN ? 2 * (IM::H1 + 1) : 0>(); else bar_dma<0>();
+  if (a.depth > 2) bar_dma<TRAIN ? SPT * (IM::H1 + 1) : 0>(); else bar_dma<0>();
   f32x16 acc;
   {
     const float* bias = reinterpret_cast<const float*>(sW + KS * 64);
@@ -366,9 +443,11 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
 
   float sse = 0.f;
   float d[3] = {0.f, 0.f, 0.f};
+  const float gscale = a.gscale;
   if (h == 0 && valid) {  // rows 0..2 of the tile live in registers 0..2 of the lower lane half
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+      if (c >= a.nout) break;   // rows >= out_features of the padded tile carry zero weights: no residual, no delta
       float o = acc[c] * a.sc_last, dfac = 1.0f;
       if (a.last_om_rev != 0.f) {   // sine output layer: d sin(om z)/dz = om cos(om z)
         const float tt = o * a.last_om_rev;
@@ -376,15 +455,17 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
         dfac = a.last_om * __builtin_amdgcn_cosf(tt);
       }
       const float p = o * 0.5f + 0.5f;  // siren.py:131
-      if (a.pred) a.pred[pix * 3 + c] = p;
+      if (a.pred) a.pred[pix * a.nout + c] = p;
       if (a.img) {
         const float r = p - tgt[c];
         sse += r * r;
-        d[c] = r * a.gscale * dfac;
+        d[c] = r * gscale * dfac;
       }
     }
   }
-  if (TRAIN) {
+  if (TRAIN && S8) {
+    a.Dlast[pb * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
+  } else if (TRAIN) {
     // dL/dout in F-layout (k-step 0: neurons PI(0,j) = j for j < 4), second k-step zero
     a.Dlast[(pb * 2 + 0) * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
     a.Dlast[(pb * 2 + 1) * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
@@ -834,6 +915,7 @@ struct ReduceArgs {
   float* gb;                        // [rows_out]
   int accumulate;                   // add to the existing gradient (later chunks)
   float scale;                      // 1 / gradient pre-scale (power of two; fp16 backward operands)
+  const float* scale_dev;           // 8-bit scratch: scale_dev[1] = 1 / (chunk pre-scale * n_values) overrides `scale`
 };
 
 // 256 threads = 16 outputs x 16 slab groups: group g sums slabs g, g+16, ... (independent loads, issued ahead),
@@ -871,7 +953,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     float t = sh[0][o];
 #pragma unroll
     for (int g = 1; g < 16; ++g) t += sh[g][o];
-    t *= a.scale;
+    t *= a.scale_dev ? a.scale_dev[1] : a.scale;
     float* dst = idx < nW ? a.gW + idx : a.gb + (idx - nW);
     *dst = a.accumulate ? *dst + t : t;
   }
@@ -881,7 +963,8 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 // layout: out[i] = sum_w slab[w][i].  256 threads = 8 float4 columns x 32 slab groups; group g sums
 // slabs g, g+32, ... in order, groups are combined 0..31 in order (fixed order => deterministic).
 __global__ __launch_bounds__(256) void k_reduce_vec(const float* slab, int n_wg, long stride, int n4, float* out,
-                                                    int accumulate, float scale) {
+                                                    int accumulate, float scale, const float* scale_dev) {
+  if (scale_dev) scale = scale_dev[1];
   __shared__ f32x4 sh[32][8];
   const int col = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const int i4 = blockIdx.x * 8 + col;
@@ -933,6 +1016,7 @@ struct AdamArgs {
   float* p; const float* g; float* m; float* v; const float* mask;
   long n;
   float beta1, beta2, eps, step_size, bc2_sqrt;
+  float omb1, omb2;   // (float)(1 - (double)beta): torch.optim.Adam forms 1 - beta in double
   const float* tab;   // graph replay mode: {step_size, bc2_sqrt} of step *iter (precomputed on the host in double)
   const int* iter;
 };
@@ -946,8 +1030,8 @@ __global__ void k_adam(AdamArgs a) {
   }
   const float g = a.g[i];
   float m = a.m[i], v = a.v[i];
-  m = m + (1.0f - a.beta1) * (g - m);
-  v = v * a.beta2 + (1.0f - a.beta2) * g * g;
+  m = m + a.omb1 * (g - m);
+  v = v * a.beta2 + a.omb2 * g * g;
   const float denom = __builtin_sqrtf(v) / a.bc2_sqrt + a.eps;
   float p = a.p[i] - a.step_size * (m / denom);
   if (a.mask) p *= a.mask[i];

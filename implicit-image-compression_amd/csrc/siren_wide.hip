@@ -122,6 +122,7 @@ struct WGemmArgs {
   const u32x4* Pprev;    // MODE 2: phases of the layer whose delta is produced (same geometry as Out)
   // MODE 1 (last layer)
   const float* img; float* pred; float gscale; float* sse_part; u32x4* Dlast; long pix0, npix;
+  int nout;              // out_features (1..3): channel count and stride of img / pred
   float last_om, last_om_rev;   // sine output layer (outermost_linear=False), 0 otherwise
   int n_super, n_ob;     // 256-pixel super-blocks of the chunk, output blocks; grid = roundup(n_super, 8) * n_ob
 };
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
   const bool valid = MODE == 1 && pix < a.npix;
   if (MODE == 1 && a.img && h == 0 && valid) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) tgt[c] = a.img[pix * 3 + c];
+    for (int c = 0; c < 3; ++c) if (c < a.nout) tgt[c] = a.img[pix * a.nout + c];
   }
   asm volatile("" ::"v"(tgt[0]), "v"(tgt[1]), "v"(tgt[2]), "v"(acc[0][0][0]));
   // B pieces are prefetched TWO chunks ahead into registers, right behind the LDS-DMA of the same chunk: vmcnt
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
     if (h == 0 && valid) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
+        if (c >= a.nout) break;
         float o = acc[0][0][c] * a.sc, dfac = 1.0f;
         if (a.last_om_rev != 0.f) {
           const float tt = o * a.last_om_rev;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
           dfac = a.last_om * __builtin_amdgcn_cosf(tt);
         }
         const float pr = o * 0.5f + 0.5f;
-        if (a.pred) a.pred[pix * 3 + c] = pr;
+        if (a.pred) a.pred[pix * a.nout + c] = pr;
         if (a.img) {
           const float r = pr - tgt[c];
           sse += r * r;

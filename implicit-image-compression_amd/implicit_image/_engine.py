@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIREN_FIT_LIB: developer override to A/B kernel variants built side by side (same C ABI)
 _LIB_PATH = os.environ.get("SIREN_FIT_LIB") or os.path.normpath(os.path.join(_HERE, "..", "csrc", "libsiren_fit.so"))
 
-SF_ABI_VERSION = 1
+SF_ABI_VERSION = 2
 DTYPES = {"bf16": 0, "f16": 1}
 
 
@@ -27,6 +27,7 @@ class sf_config(C.Structure):
         ("outermost_linear", C.c_int32), ("compute_dtype", C.c_int32),
         ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("device", C.c_int32), ("stream", C.c_void_p), ("chunk_pixels", C.c_int64),
+        ("scratch_format", C.c_int32),
     ]
 
 
@@ -54,6 +55,8 @@ def load_library():
         "sf_get_grads": [H, F], "sf_set_grads": [H, F],
         "sf_get_adam_state": [H, F, F, C.POINTER(I64)], "sf_set_adam_state": [H, F, F, I64],
         "sf_state_ptr": [H, C.c_int32, C.POINTER(C.c_void_p)],
+        "sf_sse_ptr": [H, C.POINTER(C.c_void_p)],
+        "sf_debug_scratch": [H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(I64)],
         "sf_params_changed": [H],
         "sf_set_coords": [H, F, F], "sf_set_target": [H, F],
         "sf_forward": [H, F, C.POINTER(C.c_double)],
@@ -93,8 +96,8 @@ def _check(rc: int):
 class _DevView:
     """Zero-copy torch view of engine-owned device memory via __cuda_array_interface__."""
 
-    def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    def __init__(self, ptr: int, n: int, typestr: str = "<f4"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
 def _f32_cuda(t: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
@@ -113,7 +116,7 @@ class SirenEngine:
     def __init__(self, height: int, width: int, hidden: int, depth: int, first_omega_0: float = 50.0,
                  hidden_omega_0: float = 30.0, outermost_linear: bool = True, out_features: int = 3,
                  compute_dtype: str = "f16", device: int = 0, row_begin: int = 0, row_end: int = 0,
-                 chunk_pixels: int = 0, betas=(0.9, 0.999), eps: float = 1e-8):
+                 chunk_pixels: int = 0, betas=(0.9, 0.999), eps: float = 1e-8, scratch_format: int = 0):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("SirenEngine needs a gfx950 GPU (torch.cuda.is_available() is False); no CPU fallback")
@@ -122,7 +125,7 @@ class SirenEngine:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         cfg = sf_config(SF_ABI_VERSION, height, width, row_begin, row_end, 2, out_features, hidden, depth,
                         first_omega_0, hidden_omega_0, int(bool(outermost_linear)), DTYPES[compute_dtype],
-                        betas[0], betas[1], eps, device, stream, chunk_pixels)
+                        betas[0], betas[1], eps, device, stream, chunk_pixels, scratch_format)
         self.h = C.c_void_p()
         _check(self.lib.sf_create(C.byref(cfg), C.byref(self.h)))
         n = C.c_int64()
@@ -159,6 +162,24 @@ class SirenEngine:
             _check(self.lib.sf_state_ptr(self.h, self.STATE[which], C.byref(p)))
             self._views[which] = torch.as_tensor(_DevView(p.value, self.num_params), device=self.device)
         return self._views[which]
+
+    def grad_view(self) -> torch.Tensor:
+        """The engine's own flat fp32 gradient (zero-copy): what pixel-split ranks all-reduce in place."""
+        return self.view("grads")
+
+    def sse_view(self) -> torch.Tensor:
+        """1-element float64 view of the device scalar the last pass wrote its sum of squared residuals to."""
+        if "sse" not in self._views:
+            p = C.c_void_p()
+            _check(self.lib.sf_sse_ptr(self.h, C.byref(p)))
+            self._views["sse"] = torch.as_tensor(_DevView(p.value, 1, "<f8"), device=self.device)
+        return self._views["sse"]
+
+    def debug_scratch(self, which: str) -> torch.Tensor:
+        """uint8 view of an engine scratch tensor of the last pass: phases | deltas | dlast | slabs (tests only)."""
+        p, n = C.c_void_p(), C.c_int64()
+        _check(self.lib.sf_debug_scratch(self.h, {"phases": 0, "deltas": 1, "dlast": 2, "slabs": 3}[which], C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DevView(p.value, n.value, "|u1"), device=self.device)
 
     def params_changed(self):
         _check(self.lib.sf_params_changed(self.h))

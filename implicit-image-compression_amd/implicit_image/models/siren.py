@@ -72,6 +72,7 @@ class Siren(nn.Module):
         if self._engine_width > 256 and depth < 3:
             raise NotImplementedError("hidden_size > 256 needs depth >= 3")
         self._padded = self._engine_width != hidden_size
+        self._adam = ((0.9, 0.999), 1e-8)      # torch.optim.Adam defaults; EngineAdam overrides (conf/optim/*.yaml)
         self._pad_index = None
         self._engine = None
         self._engine_key = None
@@ -79,6 +80,11 @@ class Siren(nn.Module):
         self._target_key = None
 
     # ---- engine binding -------------------------------------------------------------------
+    def set_adam_hparams(self, betas, eps: float):
+        """Adam betas / eps of the engine's fused optimiser kernel (sf_config); a live engine created with other
+        values is rebuilt on the next pass (its moments restart, as with a new torch optimiser)."""
+        self._adam = (tuple(betas), float(eps))
+
     def _param_list(self):
         """The engine's parameters in flat order: (weight, bias) of every layer.  Not `self.parameters()`:
         k-means conversion registers extra (frozen) `centroids` / `labeled_weight` parameters on the Linears."""
@@ -95,7 +101,7 @@ class Siren(nn.Module):
             raise RuntimeError("Siren runs on the gfx950 engine only: move model, grid and image to 'cuda'")
         h, w, _ = grid.shape
         H = full_height or h
-        key = (H, w, row_begin, row_end, grid.device.index)
+        key = (H, w, row_begin, row_end, grid.device.index, self._adam)
         if self._engine is None or self._engine_key != key:
             c = self.cfg
             if self._engine is not None:
@@ -103,7 +109,7 @@ class Siren(nn.Module):
             self._engine = SirenEngine(H, w, self._engine_width, c["depth"], c["first_omega_0"], c["hidden_omega_0"],
                                        c["outermost_linear"], c["output_size"], c["compute_dtype"],
                                        device=grid.device.index or 0, row_begin=row_begin, row_end=row_end,
-                                       chunk_pixels=c["chunk_pixels"])
+                                       chunk_pixels=c["chunk_pixels"], betas=self._adam[0], eps=self._adam[1])
             self._engine_key, self._grid_key, self._target_key = key, None, None
         eng = self._engine
         gkey = (grid.data_ptr(), tuple(grid.shape))
@@ -208,6 +214,7 @@ class Siren(nn.Module):
                     c["hidden_omega_0"], c["outermost_linear"], compute_dtype=c["compute_dtype"],
                     chunk_pixels=c["chunk_pixels"])
         new.to(next(self.parameters()).device)
+        new._adam = self._adam
         with torch.no_grad():
             for a, b in zip(new._param_list(), self._param_list()):
                 a.copy_(b)

@@ -27,31 +27,34 @@ def shard_jobs(jobs: Sequence, world_size: int, rank: int) -> List:
 
 class PixelSplitFit:
     """Data-parallel over pixels.  `backend` is anything with
-         forward_backward() -> float          local sum of squared residuals; leaves the local gradient
-         get_grads() -> flat fp32 tensor      local gradient, ALREADY scaled by 1/(3*H*W) of the full image
-         set_grads(flat), adam_step(lr)
-       (SirenEngine created with row_begin/row_end satisfies it).  `n_values` = 3*H*W of the full image."""
+         forward_backward(sync=False)   enqueue forward + backward of the local rows (no host sync)
+         grad_view() -> flat fp32       the backend's OWN gradient buffer, already scaled by 1/(3*H*W) of the
+                                        full image; all-reduced in place
+         sse_view()  -> float64[1]      local sum of squared residuals on the backend's device; all-reduced in place
+         adam_step(lr)
+       (SirenEngine created with row_begin/row_end satisfies it).  `n_values` = 3*H*W of the full image.
+
+    One step = two collectives on the backend's own buffers (P floats + one double), no staging copies and no host
+    synchronisation: the stream stays busy across steps, and the loss is read back only when asked for."""
 
     def __init__(self, backend, n_values: int, group=None):
         import torch.distributed as dist
         self.dist, self.backend, self.n_values, self.group = dist, backend, n_values, group
-        self._buf = None
 
-    def step(self, lr: float) -> float:
-        """One optimiser step on the full image; returns the global MSE (same on every rank)."""
-        sse = self.backend.forward_backward()
-        g = self.backend.get_grads()
-        if self._buf is None:
-            self._buf = torch.empty(g.numel() + 1, dtype=torch.float64 if g.device.type == "cpu" else torch.float32,
-                                    device=g.device)
-        self._buf[:-1].copy_(g)
-        self._buf[-1] = sse
-        if self.dist.get_backend(self.group) == "gloo" and self._buf.is_cuda:   # rehearsal path: gloo reduces on the host
-            host = self._buf.cpu()
+    def _all_reduce(self, t: torch.Tensor):
+        if self.dist.get_backend(self.group) == "gloo" and t.is_cuda:   # rehearsal path: gloo reduces on the host
+            host = t.cpu()
             self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
-            self._buf.copy_(host)
+            t.copy_(host)
         else:
-            self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM, group=self.group)
-        self.backend.set_grads(self._buf[:-1].to(g.dtype).contiguous())
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def step(self, lr: float, want_loss: bool = True):
+        """One optimiser step on the full image; returns the global MSE (same on every rank) or None."""
+        self.backend.forward_backward(sync=False)
+        sse = self.backend.sse_view()
+        self._all_reduce(self.backend.grad_view())
+        self._all_reduce(sse)
+        loss = float(sse.item()) / self.n_values if want_loss else None   # read before the next pass overwrites it
         self.backend.adam_step(lr)
-        return float(self._buf[-1].item()) / self.n_values
+        return loss

@@ -129,16 +129,20 @@ class Masking:
             if name in self.mask_dict:
                 self.mask_dict[name] = self.mask_dict[name].to(weight.device)
 
-    def _push_masks(self):
-        """Hand the current masks to the engine (flat, ones for unmasked parameters)."""
-        eng = getattr(self.module, "_engine", None)
-        if eng is None:
-            return
+    def flat_mask(self) -> torch.Tensor:
+        """Current masks as one flat 0/1 vector in named_parameters() order (ones for unmasked parameters)."""
         parts = []
         for name, weight in self.module.named_parameters():
             mk = self.mask_dict.get(name)
             parts.append((mk if mk is not None else torch.ones_like(weight)).reshape(-1).float())
-        self.module.set_engine_masks(torch.cat(parts))
+        return torch.cat(parts)
+
+    def _push_masks(self):
+        """Hand the current masks to the engine."""
+        eng = getattr(self.module, "_engine", None)
+        if eng is None:
+            return
+        self.module.set_engine_masks(self.flat_mask())
         self._pushed_engine = eng
 
     # ---- per-step (core.py:271-289, 671-702) ------------------------------------------------

@@ -32,9 +32,10 @@ class EngineAdam(Optimizer):
                  weight_decay: float = 0, amsgrad: bool = False):
         if weight_decay != 0 or amsgrad:
             raise NotImplementedError("EngineAdam supports weight_decay=0, amsgrad=False (reference defaults)")
-        if tuple(betas) != (0.9, 0.999) or eps != 1e-8:
-            raise NotImplementedError("EngineAdam uses torch.optim.Adam's default betas/eps (conf/optim/adam.yaml)")
+        if not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0 and eps >= 0.0):
+            raise ValueError(f"invalid Adam hyper-parameters betas={betas} eps={eps}")
         self.model = model
+        model.set_adam_hparams(tuple(float(b) for b in betas), float(eps))   # sf_config.beta1/beta2/eps of the engine
         super().__init__(model._param_list(), dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self._bound = None
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 1
+#define SF_ABI_VERSION 2
 
 typedef enum sf_status {
   SF_OK = 0,
@@ -71,6 +71,11 @@ typedef struct sf_config {
   int32_t device;           /* HIP device ordinal */
   void* stream;             /* hipStream_t to enqueue on (NULL = the device's null stream) */
   int64_t chunk_pixels;     /* pixels processed per kernel sweep (0 = auto) */
+  int32_t scratch_format;   /* width of the two tensors the backward re-reads from HBM (phases, deltas):
+                             * 16 = unorm16 phases + 16-bit float deltas (round-1 format);
+                             * 12 = phase BYTES + 16-bit float deltas;
+                             *  8 = phase bytes + fp8 e4m3 deltas under a per-chunk adaptive power-of-two pre-scale;
+                             *  0 = auto: 12 for hidden <= 256 with SF_F16 (8 and 12 exist only there), else 16      */
 } sf_config;
 
 typedef struct sf_engine sf_handle;
@@ -96,6 +101,13 @@ int sf_set_adam_state(sf_handle* h, const float* exp_avg_dev, const float* exp_a
 /* direct device views of engine-owned state (valid until sf_destroy); which: 0 params, 1 grads,
  * 2 exp_avg, 3 exp_avg_sq, 4 masks */
 int sf_state_ptr(sf_handle* h, int32_t which, float** dev_ptr);
+/* device address of the engine's sum-of-squared-residuals scalar (double) that the last sf_forward /
+ * sf_forward_backward wrote on the handle's stream: pixel-split ranks all-reduce it together with the gradient
+ * view instead of synchronising for the host value */
+int sf_sse_ptr(sf_handle* h, double** dev_ptr);
+/* test / debugging aid: device address and size in bytes of an engine scratch tensor of the last pass.
+ * which: 0 phases (all layers, layer stride = bytes / (depth-1)), 1 deltas, 2 dL/dout, 3 per-workgroup slabs */
+int sf_debug_scratch(sf_handle* h, int32_t which, void** dev_ptr, int64_t* bytes);
 /* tell the engine that the caller wrote the parameters through the sf_state_ptr(…,0) view */
 int sf_params_changed(sf_handle* h);
 

@@ -12,6 +12,16 @@ separate "rounding" (engine == this model to ~1e-5) from "algorithm" (this model
            by a power of two so they sit in fp16's normal range - modelled here as *2^20):
            delta_l = T((delta W*omega) * cos(2 pi q/65536)), activations re-derived as T(sin(2 pi q/65536)),
            backward weight image = T(W * omega_{l-1}); dL/dout = T(resid/(3N)); layer-0 coordinates split x = T(x) + T(x - T(x)).
+
+  scratch=12 (the default for fp16 at hidden <= 256): as above, but the phases are spilled as BYTES round(t*256) mod 256
+           and decoded as u/256 revolutions; the deltas stay 16-bit floats.
+
+  scratch=8 (sf_config.scratch_format = 8; csrc/siren_s8.hip):
+           phases spilled as bytes round(t*256) mod 256 and decoded as u/256 revolutions; dL/dout stored as
+           fp16(resid * 2^10); per pixel chunk G = 2^floor(log2(8 / rms(resid))); every hidden delta is
+           e4m3(saturate(.)) in units of G (the first one picks up G / 2^10 together with its cosine);
+           gradients of the layers below the last are scaled by float(1 / (G * 3N)), the last layer's by
+           float(1 / (2^10 * 3N)).
 """
 import math
 from typing import Sequence
@@ -35,8 +45,23 @@ def _phase_q(t):
     return torch.round(fr * 65535.0).clamp_(0, 65535)
 
 
+def _e4m3(x):
+    """OCP fp8 e4m3, round-nearest-even, saturating at +-448 (k_bwd8: v_med3_f32 + v_cvt_pk_fp8_f32)."""
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+def _phase_q8(t):
+    """phase byte of k_fwd<.., S8>: low mantissa byte of t + 1.5*2^15 = round-half-even(t * 256) mod 256."""
+    return torch.remainder(torch.round(t * 256.0), 256.0)
+
+
 def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torch.Tensor, fwd: str = "f16",
-                   first_omega_0: float = 50.0, hidden_omega_0: float = 30.0):
+                   first_omega_0: float = 50.0, hidden_omega_0: float = 30.0, scratch: int = 16,
+                   n_total: int = None):
+    if scratch == 8:
+        return _loss_and_grads_s8(params, grid, img, first_omega_0, hidden_omega_0, n_total)
+    if scratch not in (12, 16):
+        raise ValueError(scratch)
     depth = len(params) // 2
     h, w, _ = grid.shape
     n = h * w
@@ -52,7 +77,7 @@ def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torc
     a = torch.sin(TWO_PI * t.double()).float()
     for l in range(1, depth - 1):
         t = _rt(a, fwd) @ _rt(params[2 * l] * hs, fwd).t() + params[2 * l + 1] * hs   # accumulator = phase (revolutions)
-        q.append(_phase_q(t))
+        q.append(_phase_q8(t) * 256.0 if scratch == 12 else _phase_q(t))   # both decoded below as q / 65536 revolutions
         a = torch.sin(TWO_PI * t.double()).float()
     L = depth - 1
     out = (_rt(a, fwd) @ _rt(params[2 * L] * ws, fwd).t() + params[2 * L + 1] * ws) * (1.0 / ws)
@@ -77,3 +102,54 @@ def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torc
     grads[0] = delta.t() @ xh + delta.t() @ xl
     grads[1] = delta.sum(0)
     return sse / (3.0 * n), sse, grads, pred.reshape(h, w, -1)
+
+
+def _loss_and_grads_s8(params, grid, img, first_omega_0, hidden_omega_0, n_total=None):
+    """The 8-bit scratch path (fp16 operands): see the module docstring.  One pixel chunk (what every test uses)."""
+    depth = len(params) // 2
+    h, w, _ = grid.shape
+    n = h * w
+    nv = float(img.shape[-1]) * float(n_total if n_total else n)      # out_features * H * W of the full image
+    x = (grid.reshape(-1, 2) - 0.5) * 2
+    W0, b0 = params[0], params[1]
+    z = torch.addcmul(torch.addcmul(b0, x[:, 0:1], W0[:, 0]), x[:, 1:2], W0[:, 1])
+    t = z * torch.tensor(first_omega_0 / TWO_PI, dtype=torch.float32)
+    ph0 = t - torch.floor(t)
+    hs = torch.tensor(hidden_omega_0 / TWO_PI, dtype=torch.float32)
+    q = [None]
+    a = torch.sin(TWO_PI * t.double()).float()
+    for l in range(1, depth - 1):
+        t = _rt(a, "f16") @ _rt(params[2 * l] * hs, "f16").t() + params[2 * l + 1] * hs
+        q.append(_phase_q8(t))
+        a = torch.sin(TWO_PI * t.double()).float()
+    L = depth - 1
+    out = (_rt(a, "f16") @ _rt(params[2 * L] * 256.0, "f16").t() + params[2 * L + 1] * 256.0) * (1.0 / 256.0)
+    pred = out * 0.5 + 0.5
+    resid = pred - img.reshape(n, -1)
+    sse = float((resid.double() ** 2).sum())
+    S0 = 1024.0
+    dlast = _rt(resid * S0, "f16")
+    rms = min(max(math.sqrt(sse / (img.shape[-1] * n)), 1e-12), 4.0)
+    G = 2.0 ** math.floor(math.log2(8.0 / rms))
+    dfac = torch.tensor(G / S0, dtype=torch.float32)
+    sc_hidden = torch.tensor(1.0 / (G * nv), dtype=torch.float32)
+    sc_last = torch.tensor(1.0 / (S0 * nv), dtype=torch.float32)
+    grads = [None] * (2 * depth)
+    delta = dlast
+    for l in range(L, 0, -1):
+        ph = ph0 if l - 1 == 0 else q[l - 1] * (1.0 / 256.0)
+        act = _rt(torch.sin(TWO_PI * ph.double()).float(), "f16")
+        sc = sc_last if l == L else sc_hidden
+        grads[2 * l] = (delta.t() @ act) * sc
+        grads[2 * l + 1] = delta.sum(0) * sc
+        om = first_omega_0 if l - 1 == 0 else hidden_omega_0
+        Gacc = delta @ _rt(params[2 * l] * om, "f16")
+        c = torch.cos(TWO_PI * ph.double()).float()
+        if l == L:
+            c = c * dfac
+        delta = _e4m3(Gacc * c)
+    xh = _rt(x, "f16")
+    xl = _rt(x - xh, "f16")
+    grads[0] = (delta.t() @ xh + delta.t() @ xl) * sc_hidden
+    grads[1] = delta.sum(0) * sc_hidden
+    return sse / (img.shape[-1] * float(n)), sse, grads, pred.reshape(h, w, -1)

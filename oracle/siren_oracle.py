@@ -184,14 +184,14 @@ def metrics(pred: torch.Tensor, img: torch.Tensor):
     return mse.item(), psnr.item(), psnr8.item()
 
 
-def synthetic_image(height: int, width: int, seed: int = 1234) -> torch.Tensor:
+def synthetic_image(height: int, width: int, seed: int = 1234, noise: float = 0.05) -> torch.Tensor:
     """SURVEY.md §8(d) formula image (the one the golden vectors were minted on): sinusoids plus
-    seeded uniform noise of amplitude 0.05, clamped to [0,1]."""
+    seeded uniform noise of amplitude `noise` (0.05 in every round-1 fixture), clamped to [0,1]."""
     ys = torch.linspace(0, 1, height)[:, None].expand(height, width)
     xs = torch.linspace(0, 1, width)[None, :].expand(height, width)
     kx = torch.tensor([1.0, 2.0, 3.0])
     ky = torch.tensor([3.0, 1.0, 2.0])
     img = 0.5 + 0.25 * torch.sin(12 * xs[..., None] * kx) + 0.25 * torch.cos(9 * ys[..., None] * ky)
     g = torch.Generator().manual_seed(seed)
-    img = img + 0.05 * (torch.rand(height, width, 3, generator=g) * 2 - 1)
+    img = img + noise * (torch.rand(height, width, 3, generator=g) * 2 - 1)
     return img.clamp(0, 1).float().contiguous()

@@ -9,7 +9,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
 
 NAMES = [("k_fwd<256", "k_fwd"), ("k_bwd<32, 256", "k_bwd_last"), ("k_bwd<256, 256, 2, 4", "k_bwd_hidden"),
          ("k_bwd<256, 256, 2, 2", "k_bwd_hidden_layer1"), ("k_dw0<256", "k_dw_first")]
@@ -34,7 +38,8 @@ def main():
         if "FETCH_SIZE_KiB" in e and "WRITE_SIZE_KiB" in e:
             e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE_KiB"] + e["WRITE_SIZE_KiB"]) * 1024
         kernels[k] = e
-    json.dump({"source": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | SQ_*} (separate passes) -- python3 scripts/prof_step.py 2048 2",
+    json.dump({"kernel_source_sha256": kernel_source_hash(),
+               "source": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | SQ_*} (separate passes) -- python3 scripts/prof_step.py 2048 2",
                "note": "per launch at one 4 Mi-pixel chunk (2048x2048, SIREN 256x8): identical launch geometry to bench.py's "
                        "4096x4096 run with 4 Mi-pixel chunks. FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 reports "
                        "half of a wide coalesced stream, MI355X_MICROARCH.md HBM section).",

@@ -5,7 +5,15 @@ against golden vectors minted from the real reference.
 Tolerances (all stated where used):
   forward, fp16 operands   : |dpred| <= 3e-4 abs        (operand rounding 2^-11, f32 accumulate)
   forward, bf16 operands   : |dpred| <= 3e-3 abs        (2^-8)
-  gradients, fp16 operands : per-layer and total L2 error <= 5e-3 relative (measured ~1.3e-3)
+  gradients, fp16 operands, scratch_format 16 (unorm16 phases, fp16 deltas):
+                             per-layer and total L2 error <= 5e-3 relative (measured ~1.3e-3)
+  gradients, scratch_format 12 (phase BYTES; the default) and 8 (+ fp8 deltas): the quantisation is zero-mean noise
+                             that averages out over the pixels a gradient sums (measured at 256x8: 1.0e-2 on 1 280
+                             pixels, 3.0e-3 on 16 384, format 12; 3.4e-2 / 1.0e-2, format 8).  The bound is the noise
+                             the numerics model (oracle/engine_model.py, same rounding points on the CPU) shows
+                             against the fp32 reference on the same input: engine error <= 1.5 x model error + 2e-3,
+                             and the engine must equal that model to <= 3e-3 (format 12; format 8 only at depth <= 4:
+                             fp8 roundings decorrelate under 1e-6 perturbations, layer by layer)
   gradients, bf16 operands : <= 3e-2 relative (measured ~9e-3; compute_dtype="bf16" option)
   PSNR after equal steps   : |dPSNR| <= 0.05 dB          (BASELINE.json north star)
   index / mask paths       : bit-exact
@@ -19,6 +27,13 @@ import torch
 from oracle import siren_oracle as so
 
 pytestmark = pytest.mark.gpu
+
+
+FORMATS = (16, 12, 8)      # sf_config.scratch_format; 0 / default = 12 for fp16 operands at hidden <= 256
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b)))
 
 
 def _engine(H, W, hidden, depth, dtype="f16", params=None, img=None, **kw):
@@ -36,25 +51,31 @@ def _engine(H, W, hidden, depth, dtype="f16", params=None, img=None, **kw):
 
 @pytest.mark.parametrize("name,hidden,depth", [("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8),
                                                ("grads_128x6_48", 128, 6)])
-@pytest.mark.parametrize("dtype,tol,gtol", [("f16", 3e-4, 5e-3), ("bf16", 3e-3, 3e-2)])
-def test_forward_and_gradients_vs_reference_golden(golden, name, hidden, depth, dtype, tol, gtol):
+@pytest.mark.parametrize("dtype,fmt,tol,gtol", [("f16", 16, 3e-4, 5e-3), ("f16", 12, 3e-4, None), ("f16", 8, 3e-4, None),
+                                                ("bf16", 16, 3e-3, 3e-2)])
+def test_forward_and_gradients_vs_reference_golden(golden, name, hidden, depth, dtype, fmt, tol, gtol):
+    from oracle import engine_model as em
     d = golden(name)
     H, W, _ = d["img"].shape
     p = so.unflatten(d["init"], hidden, depth)
-    eng = _engine(H, W, hidden, depth, dtype, p, torch.tensor(d["img"]))
+    eng = _engine(H, W, hidden, depth, dtype, p, torch.tensor(d["img"]), scratch_format=fmt)
     pred, sse = eng.forward()
     assert np.abs(pred.cpu().numpy() - d["pred"]).max() <= tol
     assert abs(sse / (3 * H * W) - float(d["loss"])) <= 50 * tol * float(d["loss"])
     eng.forward_backward()
     g = eng.get_grads().cpu().numpy()
     ref = d["grads"]
-    assert np.linalg.norm(g - ref) <= gtol * np.linalg.norm(ref)
+    model = None
+    if gtol is None:      # byte formats: bound = the numerics model's own quantisation noise on this input
+        model = so.flatten(em.loss_and_grads(p, so.get_grid(H, W), torch.tensor(d["img"]), scratch=fmt)[2])
+    bound = lambda a, b, m: gtol if gtol is not None else 1.5 * _rel(m, b) + 2e-3
+    assert _rel(g, ref) <= bound(g, ref, model)
     off = 0
     for fin, fout in so.layer_dims(hidden, depth):
         for n in (fin * fout, fout):
             a, b = g[off:off + n], ref[off:off + n]
+            assert _rel(a, b) <= bound(a, b, None if model is None else model[off:off + n])
             off += n
-            assert np.linalg.norm(a - b) <= gtol * np.linalg.norm(b)
 
 
 @pytest.mark.parametrize("H,W,hidden,depth", [(5, 7, 32, 3), (1, 1, 64, 2), (17, 300, 64, 4), (33, 31, 128, 5)])
@@ -70,19 +91,29 @@ def test_ragged_and_tiny_grids(H, W, hidden, depth):
     assert abs(sse_e - sse) <= 2e-3 * sse
     eng.forward_backward()
     g, ref = eng.get_grads().cpu().numpy(), so.flatten(grads)
-    assert np.linalg.norm(g - ref) <= 5e-3 * np.linalg.norm(ref)
+    from oracle import engine_model as em
+    model = so.flatten(em.loss_and_grads(p, grid, img, scratch=12)[2])      # default format: phase bytes
+    if not np.isfinite(model).all():     # 1x1: the model's fixed 2^20 delta pre-scale overflows fp16 (the engine scales by N)
+        assert _rel(g, ref) <= 5e-3
+        return
+    assert _rel(g, model) <= 3e-3
+    assert _rel(g, ref) <= 1.5 * _rel(model, ref) + 2e-3
 
 
-def test_chunking_is_a_summation_order_change_only():
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_chunking_is_a_summation_order_change_only(fmt):
+    """Formats 16 / 12: every stored value is a function of its own pixel, so chunking only reorders fp32 sums.
+    Format 8 picks its power-of-two delta scale per chunk (from that chunk's residual): roundings differ, by the
+    fp8 noise itself."""
     H, W, hidden, depth = 48, 56, 128, 6
     p = so.siren_init(hidden, depth, seed=0)
     img = so.synthetic_image(H, W, seed=7)
-    a = _engine(H, W, hidden, depth, "f16", p, img)
-    b = _engine(H, W, hidden, depth, "f16", p, img, chunk_pixels=512)
+    a = _engine(H, W, hidden, depth, "f16", p, img, scratch_format=fmt)
+    b = _engine(H, W, hidden, depth, "f16", p, img, chunk_pixels=512, scratch_format=fmt)
     sa, sb = a.forward_backward(), b.forward_backward()
     assert abs(sa - sb) <= 1e-6 * sa
     ga, gb = a.get_grads(), b.get_grads()
-    assert (ga - gb).norm().item() <= 1e-5 * ga.norm().item()
+    assert (ga - gb).norm().item() <= (1e-5 if fmt != 8 else 2e-2) * ga.norm().item()
 
 
 def test_run_to_run_determinism():
@@ -149,7 +180,7 @@ def test_short_run_256x8_vs_reference(golden):
     assert np.max(np.abs(losses[:4] - d["losses"][:4]) / d["losses"][:4]) <= 2e-3
     grid, opt, model = so.get_grid(64, 64), so.Adam(p), []
     for t in range(4):
-        loss, _, grads, _ = em.loss_and_grads(p, grid, img)
+        loss, _, grads, _ = em.loss_and_grads(p, grid, img, scratch=12)
         opt.step(p, grads, lr=3e-4)
         model.append(loss)
     # beyond ~4 steps this fixture amplifies perturbations ~5x per step (measured: engine vs its own
@@ -158,23 +189,29 @@ def test_short_run_256x8_vs_reference(golden):
 
 
 @pytest.mark.parametrize("name,hidden,depth", [("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8)])
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_engine_equals_its_numerics_model(golden, name, hidden, depth, dtype):
+@pytest.mark.parametrize("dtype,fmt", [("f16", 16), ("f16", 12), ("f16", 8), ("bf16", 16)])
+def test_engine_equals_its_numerics_model(golden, name, hidden, depth, dtype, fmt):
     """Engine vs oracle/engine_model.py (identical rounding points): what remains is fp32 summation
-    order, v_sin/v_cos vs libm, and the occasional bf16 tie flipping: <= 2e-3 relative."""
+    order, v_sin/v_cos vs libm, and the occasional rounding tie flipping: <= 2e-3 relative (format 16),
+    <= 3e-3 (format 12: a phase byte that flips moves one sine by up to 2.5e-2; measured 2.4e-3 at 256x8 on 1 280
+    pixels).  Format 8 is held to the model only at depth 4: an fp8 rounding that flips is a 6 % change of that
+    delta, which flips more roundings in the next layer - at depth 8 engine and model decorrelate to the level of the
+    fp8 noise itself (measured 2.3e-2, = model vs fp32), which test_forward_and_gradients_vs_reference_golden bounds."""
     from oracle import engine_model as em
+    if fmt == 8 and depth > 4:
+        pytest.skip("fp8 delta roundings decorrelate with depth: bounded against the fp32 reference instead")
     d = golden(name)
     H, W, _ = d["img"].shape
     p = so.unflatten(d["init"], hidden, depth)
     img = torch.tensor(d["img"])
-    loss, sse, grads, pred = em.loss_and_grads(p, so.get_grid(H, W), img, fwd=dtype)
-    eng = _engine(H, W, hidden, depth, dtype, p, img)
+    loss, sse, grads, pred = em.loss_and_grads(p, so.get_grid(H, W), img, fwd=dtype, scratch=fmt)
+    eng = _engine(H, W, hidden, depth, dtype, p, img, scratch_format=fmt)
     pe, sse_e = eng.forward()
     assert (pe.cpu() - pred).abs().max().item() <= (5e-5 if dtype == "f16" else 4e-4)
     assert abs(sse_e - sse) <= 1e-4 * sse
     eng.forward_backward()
     g, ref = eng.get_grads().cpu().numpy(), so.flatten(grads)
-    assert np.linalg.norm(g - ref) <= 2e-3 * np.linalg.norm(ref)
+    assert _rel(g, ref) <= (2e-3 if fmt == 16 else 3e-3)
 
 
 def test_masks_are_applied_inside_the_step():
@@ -200,22 +237,24 @@ def test_masks_are_applied_inside_the_step():
     assert torch.all(w[torch.cat(flat) == 0] == 0)               # bit-exact: masked weights stay zero
 
 
-def test_pixel_split_handles_compose():
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_pixel_split_handles_compose(fmt):
     """Row-sharded handles (pixel-split mode): SSE and gradients of the shards add up to the
-    full-image values — the property the RCCL all-reduce path relies on."""
+    full-image values — the property the RCCL all-reduce path relies on (format 8: up to its per-shard delta
+    scale, i.e. to the fp8 noise)."""
     H, W, hidden, depth = 64, 48, 64, 4
     p = so.siren_init(hidden, depth, seed=0)
     img = so.synthetic_image(H, W, seed=4)
-    full = _engine(H, W, hidden, depth, "f16", p, img)
+    full = _engine(H, W, hidden, depth, "f16", p, img, scratch_format=fmt)
     sse = full.forward_backward()
     g = full.get_grads()
     tot, gs = 0.0, torch.zeros_like(g)
     for r0, r1 in ((0, 20), (20, 64)):
-        part = _engine(H, W, hidden, depth, "f16", p, img, row_begin=r0, row_end=r1)
+        part = _engine(H, W, hidden, depth, "f16", p, img, row_begin=r0, row_end=r1, scratch_format=fmt)
         tot += part.forward_backward()
         gs += part.get_grads()
     assert abs(tot - sse) <= 1e-6 * sse
-    assert (gs - g).norm().item() <= 1e-5 * g.norm().item()
+    assert (gs - g).norm().item() <= (1e-5 if fmt != 8 else 2e-2) * g.norm().item()
 
 
 def test_full_size_grid_properties():

@@ -68,16 +68,16 @@ class _OracleShard:
         self.p, self.grid, self.img, self.n_total = params, grid[r0:r1], img[r0:r1], grid.shape[0] * grid.shape[1]
         self.opt, self.g = so.Adam(params), None
 
-    def forward_backward(self):
+    def forward_backward(self, sync=False):
         _, sse, grads = so.loss_and_grads(self.p, self.grid, self.img, n_total=self.n_total)
         self.g = torch.tensor(so.flatten(grads))
-        return sse
+        self.sse = torch.tensor([sse], dtype=torch.float64)
 
-    def get_grads(self):
+    def grad_view(self):
         return self.g
 
-    def set_grads(self, flat):
-        self.g = flat
+    def sse_view(self):
+        return self.sse
 
     def adam_step(self, lr):
         self.opt.step(self.p, so.unflatten(self.g.numpy(), 32, 3), lr=lr)
