@@ -95,6 +95,11 @@ def fit_one(cfg: Cfg, device: torch.device, out_dir: str = None):
         quantized_model = q.convert()
         _, l, p, p8 = eval_epoch(quantized_model, grid, img)
         last.update({"Quant loss": l, "Quant PSNR": p, "Quant PSNR 8bit": p8})
+        if mask is not None:      # what fraction of the masked layers' weights the saved artefact really holds at zero
+            zeros = sum(int((w == 0).sum().item()) for n, w in quantized_model.named_parameters() if n in mask.mask_dict)
+            total = sum(w.numel() for n, w in quantized_model.named_parameters() if n in mask.mask_dict)
+            last["Quant zero fraction"] = zeros / max(total, 1)
+            last["Density"] = float(mask.stats.total_density)
         logging.info(f"Post Quant | Train step: {num_steps} | Quant step: {qcfg.num_steps} | Quant PSNR: {p:.4f}")
     if out_dir and cfg.train.save_weights:
         os.makedirs(out_dir, exist_ok=True)

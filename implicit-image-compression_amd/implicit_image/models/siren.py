@@ -43,7 +43,7 @@ class Siren(nn.Module):
     def __init__(self, input_size: int = 2, output_size: int = 3, depth: int = 8, hidden_size: int = 128,
                  first_omega_0: float = 50.0, hidden_omega_0: float = 50.0, outermost_linear: bool = True,
                  simulate_quantization: bool = False, small_dense_density: float = 1.0,
-                 compute_dtype: str = "f16", chunk_pixels: int = 0, **kwargs):
+                 compute_dtype: str = "f16", chunk_pixels: int = 0, scratch_format: int = 0, **kwargs):
         super().__init__()
         if simulate_quantization:
             raise NotImplementedError("simulate_quantization (QAT stubs) is outside the accelerated path")
@@ -57,7 +57,7 @@ class Siren(nn.Module):
         self.cfg = dict(input_size=input_size, output_size=output_size, depth=depth, hidden_size=hidden_size,
                         first_omega_0=float(first_omega_0), hidden_omega_0=float(hidden_omega_0),
                         outermost_linear=bool(outermost_linear), compute_dtype=compute_dtype,
-                        chunk_pixels=chunk_pixels)
+                        chunk_pixels=chunk_pixels, scratch_format=int(scratch_format))
         # callbacks run right before every engine pass / right after every backward: the seam the reference
         # fills with per-Linear forward-pre and backward hooks (k-means quantisation, pipeline/quant/kmeans.py:39-55)
         self.pre_pass_callbacks = []
@@ -80,6 +80,12 @@ class Siren(nn.Module):
         self._target_key = None
 
     # ---- engine binding -------------------------------------------------------------------
+    def set_scratch_format(self, fmt: int):
+        """sf_config.scratch_format of the engine (0 auto / 8 / 12 / 16); a live engine of another format is rebuilt on
+        the next pass (parameters and optimiser moments are carried over by the rebind)."""
+        if self.cfg["scratch_format"] != int(fmt):
+            self.cfg["scratch_format"] = int(fmt)
+
     def set_adam_hparams(self, betas, eps: float):
         """Adam betas / eps of the engine's fused optimiser kernel (sf_config); a live engine created with other
         values is rebuilt on the next pass (its moments restart, as with a new torch optimiser)."""
@@ -101,7 +107,7 @@ class Siren(nn.Module):
             raise RuntimeError("Siren runs on the gfx950 engine only: move model, grid and image to 'cuda'")
         h, w, _ = grid.shape
         H = full_height or h
-        key = (H, w, row_begin, row_end, grid.device.index, self._adam)
+        key = (H, w, row_begin, row_end, grid.device.index, self._adam, self.cfg["scratch_format"])
         if self._engine is None or self._engine_key != key:
             c = self.cfg
             if self._engine is not None:
@@ -109,7 +115,8 @@ class Siren(nn.Module):
             self._engine = SirenEngine(H, w, self._engine_width, c["depth"], c["first_omega_0"], c["hidden_omega_0"],
                                        c["outermost_linear"], c["output_size"], c["compute_dtype"],
                                        device=grid.device.index or 0, row_begin=row_begin, row_end=row_end,
-                                       chunk_pixels=c["chunk_pixels"], betas=self._adam[0], eps=self._adam[1])
+                                       chunk_pixels=c["chunk_pixels"], betas=self._adam[0], eps=self._adam[1],
+                                       scratch_format=c["scratch_format"])
             self._engine_key, self._grid_key, self._target_key = key, None, None
         eng = self._engine
         gkey = (grid.data_ptr(), tuple(grid.shape))
@@ -212,7 +219,7 @@ class Siren(nn.Module):
         c = self.cfg
         new = Siren(c["input_size"], c["output_size"], c["depth"], c["hidden_size"], c["first_omega_0"],
                     c["hidden_omega_0"], c["outermost_linear"], compute_dtype=c["compute_dtype"],
-                    chunk_pixels=c["chunk_pixels"])
+                    chunk_pixels=c["chunk_pixels"], scratch_format=c["scratch_format"])
         new.to(next(self.parameters()).device)
         new._adam = self._adam
         with torch.no_grad():

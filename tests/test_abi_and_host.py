@@ -127,3 +127,34 @@ def test_masking_registry_errors():
         Masking(None, None, sparse_init="nope")
     with pytest.raises(AssertionError):
         Masking(None, None, sparse_init="erdos-renyi-kernel", growth_mode="nope")
+
+
+def test_magic_division_bound_and_grid_guard():
+    """The gradient kernels decode (row, col) of local pixel p as row = (p * ceil(2^40 / W)) >> 40.  Exact while
+    p * W < 2^40 - checked here at the extremes for several widths - and
+    sf_create refuses grids beyond the bound before it touches any device (so the check runs on a CPU-only box)."""
+    import ctypes as C
+    from implicit_image import _engine
+    for W in (1, 3, 7, 300, 4096, 8191, 8192, 65535):
+        magic = ((1 << 40) + W - 1) // W
+        pmax = ((1 << 40) - 1) // W            # largest p with p * W < 2^40
+        for p in (0, 1, W - 1, W, W + 1, pmax // 2, pmax - 1, pmax):
+            if p < 0:
+                continue
+            assert (p * magic) >> 40 == p // W, (W, p)
+    W, magic = 3, ((1 << 40) + 2) // 3          # far beyond the bound the decode does break: the guard is not decoration
+    p = (1 << 41) - 1
+    assert (p * magic) >> 40 != p // W
+    lib = _engine.load_library()
+    for h, w, r0, r1, ok in ((8192, 8192, 0, 0, True), (16384, 16384, 0, 0, False), (16384, 16384, 0, 4096, False), (16384, 16384, 0, 2048, True),
+                             (65536, 16384, 0, 4095, True), (65536, 16384, 0, 4096, False)):
+        cfg = _engine.sf_config(_engine.SF_ABI_VERSION, h, w, r0, r1, 2, 3, 64, 4, 50.0, 30.0, 1, 1, 0.9, 0.999, 1e-8, 0, None, 0, 0)
+        hnd = C.c_void_p()
+        rc = lib.sf_create(C.byref(cfg), C.byref(hnd))
+        msg = lib.sf_last_error().decode()
+        if ok:      # passes the geometry guards; without a GPU it then fails on the device probe, not on the grid
+            assert rc == 0 or "grid too large" not in msg
+            if rc == 0:
+                lib.sf_destroy(hnd)
+        else:
+            assert rc == -1 and "grid too large" in msg, (h, w, r0, r1, rc, msg)

@@ -686,3 +686,201 @@ def test_config5_shape_shard_composition_and_determinism():
         part.close()
     assert abs(tot - sse) <= 1e-6 * sse
     assert (gs - g).norm().item() <= 1e-5 * g.norm().item()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: the metric model pinned at a plateau, the remaining BASELINE shapes, the index paths on the device
+# ---------------------------------------------------------------------------------------------------------
+def _fit_plateau(dtype, fmt, d):
+    S, steps, lr_step = int(d["size"]), int(d["steps"]), int(d["lr_step"])
+    img = so.synthetic_image(S, S)
+    p = so.siren_init(256, 8, seed=0)
+    assert np.array_equal(so.flatten(p)[:64], d["init_head"])          # the fixture's seed-0 init
+    eng = _engine(S, S, 256, 8, dtype, p, img, scratch_format=fmt)
+    losses = np.array(eng.step([3e-4 * 0.5 ** (t // lr_step) for t in range(steps)], want_loss=True))
+    _, sse = eng.forward(want_pred=False)
+    return 10 * math.log10(3 * S * S / sse), losses
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_psnr_parity_at_the_metric_model_plateau(golden, fmt):
+    """north-star criterion at SIREN 256x8 (BASELINE metric model): 200 full-batch steps, Adam lr 3e-4 halved every
+    40 steps, on the 256x256 formula image, against the REAL reference (tests/golden/plateau_256x8_256.npz; its own
+    8-vs-2-thread PSNR spread on this run is 0.0000 dB, stored in the fixture).  |dPSNR| <= 0.05 dB for every
+    fp16 scratch format (measured on MI355X: +0.016 / +0.012 / +0.002 dB for formats 16 / 12 / 8)."""
+    d = golden("plateau_256x8_256")
+    assert float(d["psnr_spread"]) <= 0.02
+    psnr, losses = _fit_plateau("f16", fmt, d)
+    assert abs(psnr - float(d["psnr"])) <= 0.05, (psnr, float(d["psnr"]))
+    # the first steps of this fit amplify perturbations ~5x per step (1e-3 at step 3, 5e-3 .. 9e-3 at step 4)
+    assert np.max(np.abs(losses[:4] - d["losses"][:4]) / d["losses"][:4]) <= 3e-3
+    assert abs(losses[-1] / d["losses"][-1] - 1) <= 2e-2
+
+
+def test_bf16_operands_miss_the_plateau_criterion(golden):
+    """Why compute_dtype defaults to fp16 although BASELINE.json says bf16: same run, bf16 operands.  Measured
+    +0.081 dB (8-bit significands perturb every step's gradient by ~0.4 %); the assertion records that it is outside
+    the 0.05 dB criterion the fp16 formats meet, and that it is not wildly off (a kernel bug would be)."""
+    d = golden("plateau_256x8_256")
+    psnr, _ = _fit_plateau("bf16", 16, d)
+    dev = abs(psnr - float(d["psnr"]))
+    assert 0.05 < dev <= 0.3, dev
+
+
+def _strided_grad_check(g, d, hidden, depth, tol):
+    """fixture gradients are stored every grad_stride-th element plus per-tensor L2 norms"""
+    stride = int(d["grad_stride"])
+    assert _rel(g[::stride], d["grads"]) <= tol
+    off = 0
+    norms = []
+    for fin, fout in so.layer_dims(hidden, depth):
+        for n in (fin * fout, fout):
+            norms.append(float(np.linalg.norm(g[off:off + n])))
+            off += n
+    assert np.max(np.abs(np.array(norms) / d["grad_norms"] - 1)) <= 2 * tol
+
+
+@pytest.mark.parametrize("hidden,depth,fmt", [(256, 6, 16), (256, 6, 12), (256, 6, 8), (512, 6, 0), (512, 8, 0)])
+def test_config3_shapes_vs_reference_golden(golden, hidden, depth, fmt):
+    """BASELINE config 3 networks ({256,512} x {6,8}; 256x8 is covered above) on a ragged 24x40 image: prediction,
+    loss, first-step gradient and the first 10 Adam steps against the real reference."""
+    from oracle import engine_model as em
+    d = golden(f"shapes_{hidden}x{depth}")
+    H, W, _ = d["img"].shape
+    p = so.siren_init(hidden, depth, seed=0)
+    assert np.array_equal(so.flatten(p)[:64], d["init_head"])
+    img = torch.tensor(d["img"])
+    eng = _engine(H, W, hidden, depth, "f16", p, img, scratch_format=fmt)
+    pred, sse = eng.forward()
+    assert np.abs(pred.cpu().numpy() - d["pred"]).max() <= (3e-4 if hidden <= 256 else 6e-4)
+    assert abs(sse / (3 * H * W) - float(d["loss"])) <= 2e-3 * float(d["loss"])
+    eng.forward_backward()
+    g = eng.get_grads().cpu().numpy()
+    if fmt in (12, 8):   # byte formats: the numerics model's own noise against the fp32 reference sets the bound
+        model = so.flatten(em.loss_and_grads(p, so.get_grid(H, W), img, scratch=fmt)[2])
+        tol = 1.5 * _rel(model[::int(d["grad_stride"])], d["grads"]) + 2e-3
+    else:
+        tol = 5e-3
+    _strided_grad_check(g, d, hidden, depth, tol)
+    losses = np.array(eng.step([3e-4] * 10, want_loss=True))
+    # the first steps of these over-parameterised fits amplify perturbations (see test_short_run_256x8_vs_reference)
+    assert np.max(np.abs(losses[:3] - d["losses"][:3]) / d["losses"][:3]) <= (3e-3 if fmt != 8 else 1e-2)
+    assert losses[-1] < losses[0]
+
+
+def test_rigl_at_config4_shape_vs_reference_golden(golden):
+    """BASELINE config 4 at its real shape: SIREN 256x8, RigL density 0.1 (ERK), 160 steps on 48x48 (Adam lr 3e-4
+    halved every 40 steps: the PSNR compared is a settled value), topology updates at i = 0, 20, 40, 60, 80
+    (compress.py:141-143).  mask0 bit-exact; the per-layer non-zero budget after every update, the density trace and
+    the prune-rate positions exact; PSNR within 0.05 dB of the reference, whose OWN 8-vs-2-thread runs differ by
+    0.0004 dB while already disagreeing on the masks (fixture: masks_equal_2threads = False)."""
+    from implicit_image.data import get_grid
+    from implicit_image.models import registry
+    from implicit_image.utils.train_helper import eval_epoch, get_optimizer_lr_scheduler, setup_mask, train_epoch
+    d = golden("rigl_256x8_48")
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+    H = W = 48
+    torch.manual_seed(0)
+    model = registry["siren"](depth=8, hidden_size=256, first_omega_0=50, hidden_omega_0=30).to("cuda")
+    optim, _ = get_optimizer_lr_scheduler(model, Cfg(name="adam", lr=3e-4))
+    sched = torch.optim.lr_scheduler.StepLR(optim, int(d["lr_step"]), gamma=0.5)
+    mcfg = Cfg(name="RigL", density=0.1, sparse_init="erdos-renyi-kernel", dense_gradients=True,
+               growth_mode="absolute-gradient", prune_mode="magnitude", redistribution_mode="none", dense=False,
+               prune_rate=0.1, decay_schedule="cosine", end_when=90, interval=20)
+    mask = setup_mask(model, optim, mcfg)
+    assert model.cfg["scratch_format"] == 16          # topology decisions read the dense gradient: unorm16 phases
+    names = [n for n, _ in model.named_parameters() if n in mask.mask_dict]
+
+    def bits():
+        return np.packbits(np.concatenate([mask.mask_dict[n].cpu().numpy().ravel().astype(np.uint8) for n in names]))
+    assert np.array_equal(bits(), d["mask0"])
+    img, grid = torch.tensor(d["img"]).cuda(), get_grid(H, W).cuda()
+    losses, dens, u = [], [], 0
+    for i in range(int(d["steps"])):
+        losses.append(train_epoch(model, optim, grid, img, lr_scheduler=sched, mask=mask))
+        if i <= mcfg.end_when and i % mcfg.interval == 0:
+            assert mask.prune_rate == pytest.approx(float(d[f"upd{u}_rate"]), rel=0, abs=1e-12)
+            mask.update_connections()
+            assert [int(mask.mask_dict[n].sum().item()) for n in names] == d[f"upd{u}_nnz"].tolist()   # budget per layer
+            u += 1
+        dens.append(mask.stats.total_density)
+    assert u == int(d["n_updates"]) and mask.mask_step == int(d["mask_step"])
+    assert np.allclose(dens, d["density"], rtol=0, atol=1e-12)
+    assert np.max(np.abs(np.array(losses[:5]) - d["losses"][:5]) / d["losses"][:5]) <= 3e-3
+    _, _, psnr, _ = eval_epoch(model, grid, img)
+    assert abs(psnr - float(d["psnr"])) <= 0.05, (psnr, float(d["psnr"]), float(d["psnr_spread"]))
+    for n, w in model.named_parameters():
+        if n in mask.mask_dict:
+            assert torch.all(w.data[mask.mask_dict[n] == 0] == 0)
+
+
+@pytest.mark.parametrize("hidden,depth,density", [(64, 4, 0.5), (256, 8, 0.1)])
+def test_truncate_weights_bit_exact_on_the_device(golden, hidden, depth, density):
+    """The reference's own (w, grad, mask, rate) -> (mask', w') pair replayed with every tensor ON THE GPU and bound to
+    the engine (torch.sort / comparisons run as device kernels there): magnitude prune + absolute-gradient growth must
+    reproduce the reference's masks and weights bit for bit (prune.py:24-51, grow.py:58-97)."""
+    from implicit_image.data import get_grid
+    from implicit_image.models import registry
+    from implicit_image.utils.train_helper import get_optimizer_lr_scheduler, setup_mask
+    d = golden(f"truncate_{hidden}x{depth}")
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+    torch.manual_seed(0)
+    m = registry["siren"](depth=depth, hidden_size=hidden, first_omega_0=50, hidden_omega_0=30).to("cuda")
+    opt, _ = get_optimizer_lr_scheduler(m, Cfg(name="adam", lr=3e-4))
+    mask = setup_mask(m, opt, Cfg(name="RigL", density=density, sparse_init="erdos-renyi-kernel", dense_gradients=True,
+                                  growth_mode="absolute-gradient", prune_mode="magnitude", redistribution_mode="none",
+                                  dense=False, prune_rate=0.1, decay_schedule="cosine", end_when=1500, interval=20))
+    m.engine(get_grid(16, 16).cuda())            # bind: weight.data / weight.grad become views of engine memory
+    off, moff, mbits = 0, 0, np.unpackbits(d["mask_in"])
+    for n, p in m.named_parameters():
+        k = p.numel()
+        assert p.data.is_cuda and p.grad is not None and p.grad.is_cuda
+        p.data.copy_(torch.tensor(d["w_in"][off:off + k]).view(p.shape))
+        p.grad.copy_(torch.tensor(d["g_in"][off:off + k]).view(p.shape))
+        off += k
+        if n in mask.mask_dict:
+            mask.mask_dict[n] = torch.tensor(mbits[moff:moff + k].astype(np.float32)).view(p.shape).cuda()
+            moff += k
+    mask.mask_step = int(d["mask_step_in"])
+    for s in range(mask.mask_step):
+        mask.prune_rate_decay.step(s)
+    mask.update_connections()
+    names = [n for n, _ in m.named_parameters() if n in mask.mask_dict]
+    got = np.packbits(np.concatenate([mask.mask_dict[n].cpu().numpy().ravel().astype(np.uint8) for n in names]))
+    assert np.array_equal(got, d["mask_out"])
+    flat = np.concatenate([p.detach().cpu().numpy().ravel() for p in m.parameters()]).astype(np.float32)
+    assert np.array_equal(flat, d["w_out"])
+
+
+def test_config5_one_rank_shard_of_the_8192_grid():
+    """BASELINE config 5 as ONE of its 8 ranks sees it: SIREN 1024x12 on rows [0, 1024) of the 8192 x 8192 grid
+    (W = 8192 exercises the 2^40 / W row-column decode and the 64-bit piece offsets; 8 Mi pixels in eight 1 Mi-pixel
+    chunks).  Size-independent properties: a second pass is bit-identical; the two 512-row halves add up to the
+    shard's SSE and gradient."""
+    H = W = 8192
+    R = 1024
+    p = so.siren_init(1024, 12, seed=0)
+    ys = torch.linspace(0, 1, H, device="cuda")[:R, None, None]
+    xs = torch.linspace(0, 1, W, device="cuda")[None, :, None]
+    k = torch.tensor([1.0, 2.0, 3.0], device="cuda")
+    img = (0.5 + 0.25 * torch.sin(12 * xs * k) + 0.25 * torch.cos(9 * ys * k)).contiguous()
+    full = _engine(H, W, 1024, 12, "f16", p, row_begin=0, row_end=R)
+    full.set_target(img)
+    sse = full.forward_backward()
+    g = full.get_grads().clone()
+    assert math.isfinite(sse) and torch.isfinite(g).all() and g.abs().max().item() > 0
+    assert full.forward_backward() == sse and torch.equal(full.get_grads(), g)
+    full.close()
+    tot, gs = 0.0, torch.zeros_like(g)
+    for r0, r1 in ((0, 512), (512, 1024)):
+        part = _engine(H, W, 1024, 12, "f16", p, row_begin=r0, row_end=r1)
+        part.set_target(img[r0:r1].contiguous())
+        tot += part.forward_backward()
+        gs += part.get_grads()
+        part.close()
+    assert abs(tot - sse) <= 1e-6 * sse
+    assert (gs - g).norm().item() <= 1e-5 * g.norm().item()
