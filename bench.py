@@ -125,6 +125,9 @@ def main():
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the multi-process "
                          "path with several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on a 1-GPU box: create the process group (RCCL communicator, barrier, all-reduce) "
+                         "even at WORLD_SIZE 1 - RCCL refuses two ranks on one device, gloo does not")
     ap.add_argument("--mode", default="per-image", choices=["per-image", "pixel-split"],
                     help="N>1: per-image = one independent fit per GPU (weak scaling, no collective); "
                          "pixel-split = ONE image, rows sharded over ranks, gradient all-reduce over RCCL (strong scaling)")
@@ -136,8 +139,9 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.share_gpu:
             local_rank = 0
@@ -151,7 +155,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     H = W = args.size
-    split = args.mode == "pixel-split" and world > 1
+    split = args.mode == "pixel-split" and (world > 1 or args.force_dist)
     r0, r1 = (0, H)
     if split:
         from implicit_image.parallel import PixelSplitFit, shard_rows
