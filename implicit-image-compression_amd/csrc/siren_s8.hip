@@ -234,7 +234,8 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   uint32_t ones_h2 = 0x3c003c00u;   // (1.0h, 1.0h) in a register
   asm volatile("" : "+v"(ones_h2));
   u32x4 ep_d[XT];                   // deltas of one k-step: 8 fp8 (.x .y) or 8 fp16, stored as soon as they are complete
-  uint32_t ep_pw = 0;
+  u32x2 ep_pw2 = {0u, 0u};
+  uint32_t ep_sn = 0;
   float ep_x0 = 0.f, ep_x1 = 0.f;
   // slice e of the epilogue of row tile x; bP / bS / bSx: per-step bases of the phase piece element and of the sine
   // piece elements (even / odd k-step) of row tile 0 of this wave
@@ -247,9 +248,12 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
       r0 = __builtin_fmaf(ta.y, ep_x1, __builtin_fmaf(ta.x, ep_x0, ta.z)) * a.sc_first;
       r1 = __builtin_fmaf(tb.y, ep_x1, __builtin_fmaf(tb.x, ep_x0, tb.z)) * a.sc_first;
     } else {
-      if ((v & 1) == 0) ep_pw = *(lds_cu32*)(uintptr_t)(bP + x * 1024 + 4 * (2 * q + (v >> 1)));
-      if (v & 1) { r0 = phase_rev8<2>(ep_pw); r1 = phase_rev8<3>(ep_pw); }
-      else { r0 = phase_rev8<0>(ep_pw); r1 = phase_rev8<1>(ep_pw); }
+      // 8 phase bytes of k-step q in one 8-byte read per 4 slices (a dword per 2 slices is a 4-way bank conflict at
+      // the 16-byte lane stride of a piece; 8 bytes are 2-way)
+      if (v == 0) ep_pw2 = *(__attribute__((address_space(3))) const u32x2*)(uintptr_t)(bP + x * 1024 + 8 * q);
+      const uint32_t pw = (v >> 1) ? ep_pw2.y : ep_pw2.x;
+      if (v & 1) { r0 = phase_rev8<2>(pw); r1 = phase_rev8<3>(pw); }
+      else { r0 = phase_rev8<0>(pw); r1 = phase_rev8<1>(pw); }
     }
     const int t0 = 8 * q + 2 * v;
     float c0 = __builtin_amdgcn_cosf(r0), c1 = __builtin_amdgcn_cosf(r1);
@@ -262,8 +266,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     } else {
       ep_d[x][v] = OP::pack2(g[t0] * c0, g[t0 + 1] * c1);
     }
+    // sines of two slices (4 values) leave in one 8-byte write
     const uint32_t sn = OP::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
-    *(lds_u32*)(uintptr_t)((q ? bSx : bS) + x * 2048 + q * 1024 + 4 * v) = sn;
+    if ((v & 1) == 0) ep_sn = sn;
+    else *(__attribute__((address_space(3))) u32x2*)(uintptr_t)((q ? bSx : bS) + x * 2048 + q * 1024 + 4 * (v - 1)) = u32x2{ep_sn, sn};
     if (v == 3) {   // bytes 8q .. 8q+7 of this lane's piece element
 #ifndef SF_EXPERIMENT_NO_STORE
       if (D8) reinterpret_cast<u32x2*>(&a.Dout[((pb_begin + k * pb_step) * IT + it) * 64 + lane])[q] = u32x2{ep_d[x].x, ep_d[x].y};
