@@ -92,6 +92,7 @@ struct sf_engine {
   // images
   uint16_t *wf = nullptr, *wf_last = nullptr, *wb = nullptr, *wb_last = nullptr;
   f32x4* l0tab = nullptr;
+  uint16_t* l0img = nullptr;   // layer 0 as MFMA fragments (hidden 256: k_fwd_pipe)
   float* biasw = nullptr;   // wide path: pre-scaled fp32 biases of layers 1..D-1
   bool wide = false;        // hidden > 256: layer-at-a-time kernels (siren_wide.hip)
   bool images_dirty = true;
@@ -219,6 +220,26 @@ int launch_fwd_t(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
     if (train) SF_FWD(OpBF16, true); else SF_FWD(OpBF16, false);
   }
 #undef SF_FWD
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+
+// hidden = 256, depth >= 3: the hand-scheduled software pipeline over all layers (k_fwd_pipe)
+int launch_fwd_pipe(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
+  const size_t lds = (size_t)FwdGeom(256).PIECES * 1024 + (size_t)(256 / 32) * 1024 + 64;   // weight image halves + layer-0 image + SSE partials
+  const bool f16 = h->cfg.compute_dtype == SF_F16;
+#define SF_FWDP(OP, TR, S8)                                              \
+  do {                                                                   \
+    int rc = set_lds(k_fwd_pipe<OP, TR, S8>, lds);                       \
+    if (rc) return rc;                                                   \
+    hipLaunchKernelGGL((k_fwd_pipe<OP, TR, S8>), dim3(n_super), dim3(512), lds, h->stream, a); \
+  } while (0)
+  if (f16 && train && h->s8) SF_FWDP(OpF16, true, true);
+  else if (f16 && train) SF_FWDP(OpF16, true, false);
+  else if (f16) SF_FWDP(OpF16, false, false);
+  else if (train) SF_FWDP(OpBF16, true, false);
+  else SF_FWDP(OpBF16, false, false);
+#undef SF_FWDP
   HIPCHK(hipGetLastError());
   return SF_OK;
 }
@@ -383,7 +404,11 @@ int launch_fwd(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
     case 32: return launch_fwd_t<32>(h, a, n_super, train);
     case 64: return launch_fwd_t<64>(h, a, n_super, train);
     case 128: return launch_fwd_t<128>(h, a, n_super, train);
-    case 256: return launch_fwd_t<256>(h, a, n_super, train);
+    case 256: {
+      static const bool no_pipe = getenv("SIREN_FIT_FWD_PIPE") && atoi(getenv("SIREN_FIT_FWD_PIPE")) == 0;   // A/B knob
+      if (a.depth >= 3 && !no_pipe) return launch_fwd_pipe(h, a, n_super, train);
+      return launch_fwd_t<256>(h, a, n_super, train);
+    }
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
@@ -407,6 +432,7 @@ int refresh_images(sf_engine* h) {
   a.fwd_is_f16 = h->cfg.compute_dtype == SF_F16;
   a.wf = h->wf; a.wf_last = h->wf_last; a.wb = h->wb; a.wb_last = h->wb_last;
   a.l0tab = h->l0tab;
+  a.l0img = h->l0img; a.sc_first = (float)((double)h->cfg.first_omega_0 / 6.283185307179586476925286766559);
   long n = (long)(h->D - 2) * h->WD * h->WD;
   const long n_min = (long)h->WD / 16 * 64 * 8;  // also covers the small tables
   if (n < n_min) n = n_min;
@@ -667,7 +693,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     memset(&fa, 0, sizeof(fa));
     fa.gh = h->gh; fa.gw = h->gw; fa.W = h->cfg.width; fa.row_begin = h->cfg.row_begin;
     fa.pix0 = pix0; fa.npix = h->npix; fa.depth = D;
-    fa.l0tab = h->l0tab;
+    fa.l0tab = h->l0tab; fa.l0img = reinterpret_cast<const u32x4*>(h->l0img);
     fa.wf = reinterpret_cast<const u32x4*>(h->wf);
     fa.wf_last = reinterpret_cast<const u32x4*>(h->wf_last);
     const double two_pi = 6.283185307179586476925286766559;
@@ -923,6 +949,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
     ALLOC(h->wf_last, (size_t)(WD / 16 + 1) * 1024); ALLOC(h->wb_last, (size_t)WD / 32 * 64 * 16);
   }
   ALLOC(h->l0tab, (size_t)WD * 16);
+  if (WD == 256) ALLOC(h->l0img, (size_t)(WD / 32) * 1024);
   ALLOC(h->gh, (size_t)cfg->height * 4); ALLOC(h->gw, (size_t)cfg->width * 4);
   ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->d_stride * 16);
   if (h->wide) ALLOC(h->Abuf, (size_t)(D - 1) * h->p_stride * 16);
@@ -953,8 +980,13 @@ int sf_destroy(sf_handle* h) {
   if (h->stream || true) hipStreamSynchronize(h->stream);
 #ifdef SF_EXPERIMENT_STAMP
   if (!h->wide) {
-    float dbg[16];
+    float dbg[32];
     hipMemcpy(dbg, h->sse_part + h->n_sse, sizeof(dbg), hipMemcpyDeviceToHost);
+    if (h->WD == 256)   // k_fwd_pipe
+      for (int i = 0; i < 4; ++i)
+        fprintf(stderr, "k_fwd_pipe stamp wg%d wave%d: entry->layer 0 done %.0f, wait for X1 %.0f, pipeline %.0f (barriers: mid %.0f end %.0f), tail %.0f, total %.0f cycles; entry->table barrier %.0f\n",
+                i >> 1 ? 9000 : 3, i & 1 ? 5 : 0, dbg[i * 8], dbg[i * 8 + 1], dbg[i * 8 + 2], dbg[i * 8 + 3], dbg[i * 8 + 4], dbg[i * 8 + 5], dbg[i * 8 + 6], dbg[i * 8 + 7]);
+    else
     for (int i = 0; i < 4; ++i)
       fprintf(stderr, "k_fwd stamp wg%d wave%d: hidden-layer loop %.0f cycles, barrier 1 (half X) %.0f, barrier 2 (half Y) %.0f, %d layers\n",
               i >> 1 ? 9000 : 3, i & 1 ? 5 : 0, dbg[i * 4], dbg[i * 4 + 1], dbg[i * 4 + 2], (int)dbg[i * 4 + 3]);
@@ -972,7 +1004,7 @@ int sf_destroy(sf_handle* h) {
 #endif
   for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab,
+  void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab, h->l0img,
                   h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part, h->biasw, h->Abuf,
                   h->sse_dev, h->scale_dev};
   for (void* p : ptrs) if (p) hipFree(p);

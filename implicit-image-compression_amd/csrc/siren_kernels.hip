@@ -209,6 +209,16 @@ DEV void glds16s(const void* sbase, uint32_t lane_off_bytes, char* lds_wave_base
 }
 
 
+// same, with everything precomputed: wave-uniform image base (SGPR pair), byte offset inside the image (VGPR), LDS byte
+// address of the destination piece (SGPR)
+DEV void glds16o(const void* sbase, uint32_t off_bytes, uint32_t lds_addr) {
+#ifdef SF_EXPERIMENT_NO_DMA
+  return;
+#endif
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(lds_addr), "v"(off_bytes), "s"(sbase) : "memory", "m0");
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_fwd
 // ---------------------------------------------------------------------------------------------
@@ -221,6 +231,7 @@ struct FwdArgs {
   long npix;               // local pixels of the handle (valid: pix < npix)
   int depth;               // number of Linear layers
   const f32x4* l0tab;      // [WD] {w00, w01, b0, 0}
+  const u32x4* l0img;      // k_fwd_pipe: layer 0 as ONE MFMA k-step per 32-neuron tile (WD/32 pieces, see kL0Split)
   const u32x4* wf;         // (depth-2) forward images (FwdImg<WD>::PIECES pieces each, biases included)
   const u32x4* wf_last;    // forward image of the last layer padded to 32 rows + bias piece
   float sc_first;          // first_omega_0 / (2 pi)
@@ -260,6 +271,52 @@ struct FwdImg {
   static __host__ __device__ constexpr int bias_piece(int nt) { return nt < H0 ? H0 * KS : X_PIECES + H1 * KS; }
   static __host__ __device__ constexpr int bias_off(int nt) { return (nt < H0 ? nt : nt - H0) * 32; }
 };
+
+// last-layer accumulator -> prediction, residual, dL/dout piece and the workgroup's SSE partial (shared by k_fwd and
+// k_fwd_pipe; called by all 512 threads)
+template <typename OP, bool TRAIN, bool S8>
+DEV void fwd_tail(const FwdArgs& a, const f32x16& acc, const float (&tgt)[3], long pix, long pb, bool valid, int lane, int h,
+                  int wave, int tid, float* sRed) {
+  float sse = 0.f;
+  float d[3] = {0.f, 0.f, 0.f};
+  const float gscale = a.gscale;
+  if (h == 0 && valid) {  // rows 0..2 of the tile live in registers 0..2 of the lower lane half
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (c >= a.nout) break;   // rows >= out_features of the padded tile carry zero weights: no residual, no delta
+      float o = acc[c] * a.sc_last, dfac = 1.0f;
+      if (a.last_om_rev != 0.f) {   // sine output layer: d sin(om z)/dz = om cos(om z)
+        const float tt = o * a.last_om_rev;
+        o = __builtin_amdgcn_sinf(tt);
+        dfac = a.last_om * __builtin_amdgcn_cosf(tt);
+      }
+      const float p = o * 0.5f + 0.5f;  // siren.py:131
+      if (a.pred) a.pred[pix * a.nout + c] = p;
+      if (a.img) {
+        const float r = p - tgt[c];
+        sse += r * r;
+        d[c] = r * gscale * dfac;
+      }
+    }
+  }
+  if (TRAIN && S8) {
+    a.Dlast[pb * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
+  } else if (TRAIN) {
+    // dL/dout in F-layout (k-step 0: neurons PI(0,j) = j for j < 4), second k-step zero
+    a.Dlast[(pb * 2 + 0) * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
+    a.Dlast[(pb * 2 + 1) * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
+  }
+  // workgroup SSE partial (fixed order: lanes by xor-shuffle, then waves 0..7)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
+  if (lane == 0) sRed[wave] = sse;
+  __syncthreads();
+  if (tid == 0 && a.sse_part) {
+    float t = 0.f;
+    for (int w = 0; w < kWavesFwd; ++w) t += sRed[w];
+    a.sse_part[blockIdx.x] = t;
+  }
+}
 
 template <int WD, typename OP, bool TRAIN, bool S8 = false>
 __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
@@ -441,45 +498,346 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
 #pragma unroll
   for (int s = 0; s < KS; ++s) acc = OP::mfma(sW[s * 64 + lane], B[s], acc);
 
-  float sse = 0.f;
-  float d[3] = {0.f, 0.f, 0.f};
-  const float gscale = a.gscale;
-  if (h == 0 && valid) {  // rows 0..2 of the tile live in registers 0..2 of the lower lane half
+  fwd_tail<OP, TRAIN, S8>(a, acc, tgt, pix, pb, valid, lane, h, wave, tid, sRed);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fwd_pipe: k_fwd for hidden = 256 and depth >= 3 as ONE software pipeline over all hidden layers.
+//
+// k_fwd leaves the order of a tile's 16 MFMAs, its 16 weight-fragment reads and the previous tile's sine epilogue to
+// hipcc, which reads two fragments, waits for them, issues two MFMAs (ten times per tile, LDS latency exposed every
+// time) and packs the whole epilogue behind the last six: the matrix pipe was busy 54 % of the time.  Here the order is
+// fixed by hand, one "slot" per MFMA, and nothing crosses a slot boundary (sched_barrier):
+//
+//   slot g of a layer (g = 16 * tile + k-step):   read fragment g + PD (LDS -> registers, PD slots ahead)
+//                                                 MFMA g
+//                                                 1-2 values of the previous tile's epilogue (sin, phase byte, pack)
+//                                                 [slot 12 of a tile: the next tile's bias = its accumulator]
+//
+// The pipeline never drains: the fragment ring, the bias-initialised accumulator and the epilogue of a layer's LAST tile
+// carry over into the first tile of the next layer (that epilogue produces k-steps 14 and 15 of the activations, which
+// tile 0 needs at its slots 14 and 15 only, so it runs in slots 1..13), and finally into the 16 MFMAs of the output
+// layer.  Layer 0 enters the same way: its last 32 neurons are handed over as phases in `prev`, and the generic epilogue
+// takes their sines (their phase bytes go to the unused layer-0 plane of the scratch, which keeps the store counts of
+// the vmcnt waits uniform).  The two workgroup barriers per layer sit where the READS move from one half of the LDS
+// weight image to the other (PD slots before the MFMAs do), so the wave still holds PD ready fragments after a barrier.
+// Activations ping-pong between two register arrays (the layer loop is unrolled by two): no copies.
+// The compiler still places every s_waitcnt lgkmcnt itself, from the fixed order.
+// ---------------------------------------------------------------------------------------------
+// Layer 0 on the matrix pipe (k_fwd_pipe).  z = (w0 x0 + w1 x1 + b) * first_omega_0 / (2 pi) needs f32 accuracy (the
+// coordinates alone carry 12+ bits), so both factors are split into two 16-bit floats, a = ah + al, and the k-step sums
+// the products that matter, each pair scaled by a power of two so that its small factor stays a normal number:
+//   k:   0        1          2          3        4          5          6      7
+//   A:   w0h      w0h / S    w0l * S    w1h      w1h / S    w1l * S    bh     bl * S        (lane half 0; half 1: zeros)
+//   B:   x0h      x0l * S    x0h / S    x1h      x1l * S    x1h / S    1      1 / S
+// (w, b pre-multiplied by omega/(2 pi)); the dropped wl*xl terms are < 2^-22 of |w x|.  Always fp16, also when the
+// hidden layers run on bf16 operands.
+constexpr float kL0Split = 64.0f;
+DEV void split_f16(float x, float lo_scale, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * lo_scale);
+}
+DEV uint32_t pack_h2(_Float16 a, _Float16 b) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  return __builtin_bit_cast(uint32_t, h2{a, b});
+}
+
+#ifndef SF_FWD_PD
+#define SF_FWD_PD 4
+#endif
+template <typename OP, bool TRAIN, bool S8, int PD = SF_FWD_PD>
+__global__ __launch_bounds__(512) void k_fwd_pipe(FwdArgs a) {
+  constexpr int WD = 256;
+  using IM = FwdImg<WD>;
+  constexpr int NT = IM::NT, KS = IM::KS, H0 = IM::H0, NG = NT * KS;
+  constexpr int SPT = S8 ? 1 : 2;                       // phase stores per tile epilogue
+  constexpr int ST_SLOT = KS - 3;                       // slot of a tile in which the previous tile's phases are stored
+  // The weight DMA is spread out: a wave issues its (up to) 9 pieces of a half image one every DSP slots, starting
+  // DMA0 slots into the half that follows the barrier which freed the LDS region (a burst of 8-9 global_load_lds
+  // right behind the barrier cost each wave ~200 cycles per piece with both waves of a SIMD in it at once: the whole
+  // staging was 25 % of the kernel).  NST = phase stores a wave issues between its last piece and the barrier that
+  // waits for the image (slots 13 and 29 of a half lie behind the last DMA slot 26; slot 45 .. behind the barrier).
+  constexpr int DMA0 = 2, DSP = 3, NPC = 9;
+  constexpr int NST = TRAIN ? SPT * 2 : 0;
+  static_assert(DMA0 + DSP * (NPC - 1) < ST_SLOT + KS && DMA0 + DSP * (NPC - 1) > ST_SLOT && (ST_SLOT - DMA0) % DSP != 0 &&
+                NPC * kWavesFwd >= IM::X_PIECES && NPC * kWavesFwd >= IM::Y_PIECES, "DMA slot plan");
+  static_assert(2 * H0 == NT && PD >= 3 && PD <= 8 && KS == 16, "slot plan: barrier slot KS - PD <= bias slot KS - 4 < store slot KS - 3");
+#ifdef SF_EXPERIMENT_STAMP
+  const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+  unsigned long long st_mid = 0, st_end = 0, st_l0 = 0, st_x1 = 0, st_loop = 0;
+#endif
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* sW = reinterpret_cast<u32x4*>(smem);
+  u32x4* sL0 = reinterpret_cast<u32x4*>(smem + (size_t)IM::PIECES * 1024);     // layer-0 image: NT pieces
+  float* sRed = reinterpret_cast<float*>(sL0 + NT * 64);
+  static_assert(NT == kWavesFwd, "one layer-0 piece per wave");
+
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto stage = [&](const u32x4* src, int dst, int n) {
+    for (int pc = wave; pc < n; pc += kWavesFwd) glds16s(src + pc * 64, (uint32_t)lane * 16u, smem + (size_t)(dst + pc) * 1024);
+  };
+  const long pb = (long)blockIdx.x * kWavesFwd + wave;
+  const long pix = a.pix0 + pb * 32 + m;
+  const bool valid = pix < a.npix;
+  const long pc = valid ? pix : a.npix - 1;
+  const int row = (int)(pc / a.W), col = (int)(pc - (long)row * a.W);
+  const float x0 = (a.gh[a.row_begin + row] - 0.5f) * 2.0f;  // siren.py:128
+  const float x1 = (a.gw[col] - 0.5f) * 2.0f;
+  float tgt[3] = {0.f, 0.f, 0.f};
+  if (a.img && h == 0 && valid) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (c >= a.nout) break;   // rows >= out_features of the padded tile carry zero weights: no residual, no delta
-      float o = acc[c] * a.sc_last, dfac = 1.0f;
-      if (a.last_om_rev != 0.f) {   // sine output layer: d sin(om z)/dz = om cos(om z)
-        const float tt = o * a.last_om_rev;
-        o = __builtin_amdgcn_sinf(tt);
-        dfac = a.last_om * __builtin_amdgcn_cosf(tt);
+    for (int c = 0; c < 3; ++c) if (c < a.nout) tgt[c] = a.img[pix * a.nout + c];
+  }
+  asm volatile("" :: "v"(x0), "v"(x1), "v"(tgt[0]), "v"(tgt[1]), "v"(tgt[2]));
+  const int L = a.depth - 2;                      // hidden layers (>= 1: the host sends depth 2 to k_fwd)
+  glds16s(a.l0img + wave * 64, (uint32_t)lane * 16u, reinterpret_cast<char*>(sL0) + (size_t)wave * 1024);
+  stage(a.wf, 0, IM::X_PIECES);
+  asm volatile("" ::: "memory");
+  // B operand of layer 0 (see kL0Split)
+  u32x4 bx = u32x4{0u, 0u, 0u, 0u};
+  {
+    _Float16 x0h, x0l, x1h, x1l;
+    split_f16(x0, kL0Split, x0h, x0l);
+    split_f16(x1, kL0Split, x1h, x1l);
+    const _Float16 x0s = (_Float16)((float)x0h * (1.0f / kL0Split)), x1s = (_Float16)((float)x1h * (1.0f / kL0Split));
+    if (h == 0) bx = u32x4{pack_h2(x0h, x0l), pack_h2(x0s, x1h), pack_h2(x1l, x1s), pack_h2((_Float16)1.0f, (_Float16)(1.0f / kL0Split))};
+  }
+  bar_dma<IM::X_PIECES / kWavesFwd>();   // the layer-0 piece (issued first) landed; the X pieces behind it may stay in flight
+#ifdef SF_EXPERIMENT_STAMP
+  const unsigned long long st_tab = __builtin_amdgcn_s_memtime();
+#endif
+
+  auto slot_end = [&]() {   // nothing moves across: neither memory operations (compiler) nor instructions (scheduler)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  u32x4 Ba[KS], Bb[KS];
+  f32x16 prev, cur;
+  // ---- layer 0: one fp16 MFMA per tile (phases in revolutions), sines of tiles 0..6 -> k-steps 0..13 of Ba; the last
+  // tile is handed to the pipeline as phases in `prev` (its sines are taken by the first slots of layer 1)
+  {
+    auto l0_tile = [&](int nt) {
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, sL0[nt * 64 + lane]), __builtin_bit_cast(f16x8, bx),  // (prologue only)
+                                                    f32x16{}, 0, 0, 0);
+    };
+    f32x16 z = l0_tile(0);
+#pragma unroll
+    for (int nt = 1; nt < NT; ++nt) {
+      const f32x16 zn = l0_tile(nt);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          w[j] = OP::pack2(__builtin_amdgcn_sinf(z[8 * q + 2 * j]), __builtin_amdgcn_sinf(z[8 * q + 2 * j + 1]));
+          asm volatile("" : "+v"(w[j]));   // pinned to this tile (MachineSink would carry the phases down to their first use)
+        }
+        Ba[2 * (nt - 1) + q] = u32x4{w[0], w[1], w[2], w[3]};
       }
-      const float p = o * 0.5f + 0.5f;  // siren.py:131
-      if (a.pred) a.pred[pix * a.nout + c] = p;
-      if (a.img) {
-        const float r = p - tgt[c];
-        sse += r * r;
-        d[c] = r * gscale * dfac;
+      slot_end();
+      z = zn;
+    }
+    prev = z;
+  }
+
+  // Explicit LDS addressing: five per-lane base registers, everything else is the 16-bit immediate of the read.  (Left
+  // to itself hipcc gave every piece beyond the first 64 KiB its own loop-invariant address register - 56 of them - and
+  // spilled what the pipeline needs.)  The empty asm makes a base opaque, so constants are not folded back into it.
+  typedef __attribute__((address_space(3))) const u32x4 lds_cv4;
+  typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+  __builtin_assume(wave >= 0 && wave < kWavesFwd);
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  const uint32_t lds_wave = lds0 + (uint32_t)wave * 1024u;         // LDS-DMA: destination of piece `wave`
+  uint32_t aXf = lds0 + lane16;                                               // fragments of half X / the output layer
+  uint32_t aYf = lds0 + (uint32_t)IM::X_PIECES * 1024u + lane16;              // fragments of half Y
+  uint32_t aXb = lds0 + (uint32_t)IM::bias_piece(0) * 1024u + (uint32_t)h * 16u;     // bias piece of half X
+  uint32_t aYb = lds0 + (uint32_t)IM::bias_piece(H0) * 1024u + (uint32_t)h * 16u;    // bias piece of half Y
+  uint32_t aLb = lds0 + (uint32_t)KS * 1024u + (uint32_t)h * 16u;                    // bias piece of the output layer
+  asm volatile("" : "+v"(aXf), "+v"(aYf), "+v"(aXb), "+v"(aYb), "+v"(aLb));
+  auto frag = [&](int nt, int s2) -> u32x4 {   // fragment (tile, k-step) of the hidden image in LDS
+    return nt < H0 ? *(lds_cv4*)(uintptr_t)(aXf + (uint32_t)(nt * KS + s2) * 1024u)
+                   : *(lds_cv4*)(uintptr_t)(aYf + (uint32_t)((nt - H0) * KS + s2) * 1024u);
+  };
+  auto tile_bias = [&](uint32_t ab, int q4, f32x16& acc) {
+    const f32x4 b = *(lds_cf4*)(uintptr_t)(ab + (uint32_t)q4 * 32u);
+    acc[4 * q4 + 0] = b.x; acc[4 * q4 + 1] = b.y; acc[4 * q4 + 2] = b.z; acc[4 * q4 + 3] = b.w;
+  };
+  auto hidden_bias = [&](int nt) -> uint32_t { return (nt < H0 ? aXb : aYb) + (uint32_t)IM::bias_off(nt) * 4u; };
+
+#ifdef SF_EXPERIMENT_STAMP
+  st_l0 = __builtin_amdgcn_s_memtime();
+#endif
+  bar_dma<0>();                                            // half X of layer 1 landed
+#ifdef SF_EXPERIMENT_STAMP
+  st_x1 = __builtin_amdgcn_s_memtime();
+#endif
+  u32x4 fr[PD];                                            // fragments 0..PD-1 of the upcoming tile 0
+#pragma unroll
+  for (int i = 0; i < PD; ++i) fr[i] = frag(0, i);
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) tile_bias(hidden_bias(0), q4, cur);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  // epilogue values e of accumulator `acc` -> sines into the two k-steps dst[0], dst[1] and phases into HBM.
+  // Slot plan: none in slot 0 (the matrix pipe is still writing acc), two per slot in slots 1..3, one in 4..13.
+  struct Epi { float av[16]; float ph[16]; uint32_t pb8[4]; u32x4 pw[2]; };
+  auto epi_value = [&](Epi& E, const f32x16& acc, int e, u32x4* dst) {
+    const float tt = acc[e];
+#ifdef SF_EXPERIMENT_FWD_NO_EPI   // timing-only build: no sine, no phase byte (one pack per two values remains)
+    E.av[e] = tt;
+    if (e & 1) dst[e >> 3][(e & 7) >> 1] = OP::pack2(E.av[e - 1], E.av[e]);
+    E.pb8[e >> 2] = __builtin_bit_cast(uint32_t, tt);
+    return;
+#endif
+    E.av[e] = __builtin_amdgcn_sinf(tt);
+    if constexpr (TRAIN && S8) {
+      switch (e & 3) {
+        case 0: phase_byte<0>(E.pb8[e >> 2], tt, E.av[e]); break;
+        case 1: phase_byte<1>(E.pb8[e >> 2], tt, E.av[e]); break;
+        case 2: phase_byte<2>(E.pb8[e >> 2], tt, E.av[e]); break;
+        default: phase_byte<3>(E.pb8[e >> 2], tt, E.av[e]); break;
+      }
+    } else if constexpr (TRAIN) {
+      E.ph[e] = __builtin_amdgcn_fractf(tt);
+    }
+    if (e & 1) {
+      // the empty asm pins the pack to its slot: MachineSink would otherwise move it (and the two f32 sines it
+      // frees) down to the next layer's first use, across every slot boundary
+      uint32_t w = OP::pack2(E.av[e - 1], E.av[e]);
+      asm volatile("" : "+v"(w));
+      dst[e >> 3][(e & 7) >> 1] = w;
+      if constexpr (TRAIN && !S8) {
+        uint32_t p2 = pack_phase2(E.ph[e - 1], E.ph[e]);
+        asm volatile("" : "+v"(p2));
+        E.pw[e >> 3][(e & 7) >> 1] = p2;
       }
     }
-  }
-  if (TRAIN && S8) {
-    a.Dlast[pb * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
-  } else if (TRAIN) {
-    // dL/dout in F-layout (k-step 0: neurons PI(0,j) = j for j < 4), second k-step zero
-    a.Dlast[(pb * 2 + 0) * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
-    a.Dlast[(pb * 2 + 1) * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
-  }
-  // workgroup SSE partial (fixed order: lanes by xor-shuffle, then waves 0..7)
+  };
+  auto epi_slot = [&](Epi& E, const f32x16& acc, int s, u32x4* dst, u32x4* ptile) {
+    if (s >= 1 && s <= 3) { epi_value(E, acc, 2 * s - 2, dst); epi_value(E, acc, 2 * s - 1, dst); }
+    if (s >= 4 && s <= 13) epi_value(E, acc, s + 2, dst);
+    if (TRAIN && s == ST_SLOT) {
+      if constexpr (S8) store_stream(ptile, u32x4{E.pb8[0], E.pb8[1], E.pb8[2], E.pb8[3]});
+      else { store_stream(ptile, E.pw[0]); store_stream(ptile + 64, E.pw[1]); }
+    }
+  };
+  constexpr int PPT = S8 ? 1 : 2;                         // phase pieces per (pixel block, tile)
+
+  // one hidden layer l: reads activations Bi, writes Bo (k-steps 0..13; 14 and 15 follow in the next stage)
+  auto layer = [&](u32x4 (&Bi)[KS], u32x4 (&Bo)[KS], int l) {
+    const bool more = l < L;
+    const u32x4* srcY = a.wf + ((size_t)(l - 1) * IM::PIECES + IM::X_PIECES) * 64;     // half Y of this layer
+    const u32x4* srcX = more ? a.wf + (size_t)l * IM::PIECES * 64 : a.wf_last;        // half X of layer l + 1 / output layer
+    const int nX = more ? IM::X_PIECES : IM::LAST_PIECES;
+    u32x4* pl = a.P + (size_t)l * a.p_stride + (size_t)pb * (NT * PPT) * 64 + lane;   // phases of layer l, this pixel block
+    const uint32_t bias_next0 = more ? hidden_bias(0) : aLb;
+    u32x4 ring[NG + PD];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
-  if (lane == 0) sRed[wave] = sse;
-  __syncthreads();
-  if (tid == 0 && a.sse_part) {
-    float t = 0.f;
-    for (int w = 0; w < kWavesFwd; ++w) t += sRed[w];
-    a.sse_part[blockIdx.x] = t;
+    for (int i = 0; i < PD; ++i) ring[i] = fr[i];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      Epi E;
+      f32x16 nxt;
+      u32x4* dst = nt == 0 ? &Bi[KS - 2] : &Bo[2 * (nt - 1)];
+      u32x4* ptile = nt == 0 ? pl - a.p_stride + (NT - 1) * PPT * 64 : pl + (nt - 1) * PPT * 64;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int g = nt * KS + s;
+        if (g == NG / 2 - PD) {        // every read of half X is issued: half Y landed, everyone left half X
+#ifdef SF_EXPERIMENT_STAMP
+          const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef SF_EXPERIMENT_FWD_NO_BAR
+          bar_dma<NST>();
+#endif
+#ifdef SF_EXPERIMENT_STAMP
+          st_mid += __builtin_amdgcn_s_memtime() - t_a;
+#endif
+        }
+        if (g == NG - PD) {            // every read of half Y is issued: the next layer's half X landed
+#ifdef SF_EXPERIMENT_STAMP
+          const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef SF_EXPERIMENT_FWD_NO_BAR
+          bar_dma<NST>();
+#endif
+#ifdef SF_EXPERIMENT_STAMP
+          st_end += __builtin_amdgcn_s_memtime() - t_a;
+#endif
+        }
+        {   // one piece of the image that goes into the LDS half everyone left at the last barrier
+          const int r = g % (NG / 2);          // slot within this half of the layer
+          if (r >= DMA0 && (r - DMA0) % DSP == 0 && (r - DMA0) / DSP < NPC) {
+            // piece wave + 8 i: the piece offset goes into the SGPR address pair and into M0 (SALU only); the one VGPR
+            // operand is the lane offset every LDS access of the kernel already uses
+            const int i8 = kWavesFwd * ((r - DMA0) / DSP), pc = wave + i8;
+            if (g < NG / 2) {
+              if (pc < IM::Y_PIECES) glds16o(srcY + (size_t)pc * 64, lane16, lds_wave + (uint32_t)(IM::X_PIECES + i8) * 1024u);
+            } else {
+              if (pc < nX) glds16o(srcX + (size_t)pc * 64, lane16, lds_wave + (uint32_t)i8 * 1024u);
+            }
+          }
+        }
+        const int f = g + PD;
+        ring[f] = f < NG ? frag(f / KS, f % KS) : frag(0, f - NG);    // (f >= NG: tile 0 of the next layer / the output layer)
+        cur = OP::mfma(ring[g], Bi[s], cur);
+        epi_slot(E, prev, s, dst, ptile);
+        if (s == KS - 4) {   // the next tile's bias = its accumulator: right behind the barrier slot, four MFMAs before its use
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) tile_bias(nt + 1 < NT ? hidden_bias(nt + 1) : bias_next0, q4, nxt);
+        }
+        slot_end();
+      }
+      prev = cur;
+      cur = nxt;
+    }
+#pragma unroll
+    for (int i = 0; i < PD; ++i) fr[i] = ring[NG + i];
+  };
+  // output layer (one 32-row tile) under the epilogue of the last hidden tile
+  f32x16 acc;
+  auto output_layer = [&](u32x4 (&Bi)[KS]) {
+    u32x4* ptile = a.P + (size_t)L * a.p_stride + ((size_t)pb * NT + (NT - 1)) * PPT * 64 + lane;
+    u32x4 ring[KS + PD];
+    Epi E;
+#pragma unroll
+    for (int i = 0; i < PD; ++i) ring[i] = fr[i];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + PD < KS) ring[s + PD] = frag(0, s + PD);
+      cur = OP::mfma(ring[s], Bi[s], cur);
+      epi_slot(E, prev, s, &Bi[KS - 2], ptile);
+      slot_end();
+    }
+    acc = cur;
+  };
+  // (no exit between the two layers of a pair: the live ring would have to be spilled for it on every iteration)
+  int l = 1;
+  for (; l + 1 <= L; l += 2) {
+    layer(Ba, Bb, l);
+    layer(Bb, Ba, l + 1);
   }
+  if (l == L) {
+    layer(Ba, Bb, l);
+    output_layer(Bb);
+  } else {
+    output_layer(Ba);
+  }
+#ifdef SF_EXPERIMENT_STAMP
+  st_loop = __builtin_amdgcn_s_memtime();
+#endif
+  fwd_tail<OP, TRAIN, S8>(a, acc, tgt, pix, pb, valid, lane, h, wave, tid, sRed);
+#ifdef SF_EXPERIMENT_STAMP
+  if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 9000)) {
+    float* o = a.dbg + ((blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 8;
+    const unsigned long long st_exit = __builtin_amdgcn_s_memtime();
+    o[0] = (float)(st_l0 - st_entry); o[1] = (float)(st_x1 - st_l0); o[2] = (float)(st_loop - st_x1); o[3] = (float)st_mid;
+    o[4] = (float)st_end; o[5] = (float)(st_exit - st_loop); o[6] = (float)(st_exit - st_entry); o[7] = (float)(st_tab - st_entry);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1053,6 +1411,8 @@ struct ImgArgs {
   int fwd_is_f16;
   uint16_t* wf; uint16_t* wf_last; uint16_t* wb; uint16_t* wb_last;
   f32x4* l0tab;
+  uint16_t* l0img;          // layer 0 as MFMA A fragments (k_fwd_pipe, see kL0Split), always fp16; nullptr: not built
+  float sc_first;           // first_omega_0 / (2 pi)
 };
 DEV uint16_t to_bf16(float x) { return (uint16_t)(OpBF16::pack2(x, 0.f) & 0xffffu); }
 DEV uint16_t to_f16(float x) { return (uint16_t)(OpF16::pack2(x, 0.f) & 0xffffu); }
@@ -1124,6 +1484,20 @@ __global__ void k_images(ImgArgs a) {
   if (gid < WD) {
     const float* W0 = a.params + a.off_w[0];
     a.l0tab[gid] = f32x4{W0[gid * 2], W0[gid * 2 + 1], a.params[a.off_b[0] + gid], 0.f};
+  }
+  if (a.l0img && gid < (long)NT * 64) {   // one lane (8 halves) of the layer-0 image per thread
+    const int lane = (int)(gid & 63), tile = (int)(gid >> 6), r = lane & 31, n = 32 * tile + r;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if ((lane >> 5) == 0) {
+      const float* W0 = a.params + a.off_w[0];
+      _Float16 h0, l0, h1, l1, hb, lb;
+      split_f16(W0[n * 2] * a.sc_first, kL0Split, h0, l0);
+      split_f16(W0[n * 2 + 1] * a.sc_first, kL0Split, h1, l1);
+      split_f16(a.params[a.off_b[0] + n] * a.sc_first, kL0Split, hb, lb);
+      const _Float16 s0 = (_Float16)((float)h0 * (1.0f / kL0Split)), s1 = (_Float16)((float)h1 * (1.0f / kL0Split));
+      v = u32x4{pack_h2(h0, s0), pack_h2(l0, h1), pack_h2(s1, l1), pack_h2(hb, lb)};
+    }
+    reinterpret_cast<u32x4*>(a.l0img)[gid] = v;
   }
 }
 

@@ -183,18 +183,23 @@ def test_short_run_256x8_vs_reference(golden):
         loss, _, grads, _ = em.loss_and_grads(p, grid, img, scratch=12)
         opt.step(p, grads, lr=3e-4)
         model.append(loss)
-    # beyond ~4 steps this fixture amplifies perturbations ~5x per step (measured: engine vs its own
-    # numerics model 6e-4 at step 3, 3e-2 at step 6), so later steps carry no parity information
-    assert np.max(np.abs(losses[:4] - np.array(model)) / np.array(model)) <= 1e-3, (losses, model)
+    # this fixture amplifies perturbations ~5x per step (measured: engine vs its own numerics model 2e-7, 8e-5, 2e-4,
+    # 6e-4 .. 1.0e-3 at steps 0..3 depending on last-bit details of layer 0, 3e-2 at step 6), so the fourth step gets
+    # the bound of the reference curve and later steps carry no parity information
+    rel = np.abs(losses[:4] - np.array(model)) / np.array(model)
+    assert np.max(rel[:3]) <= 5e-4 and rel[3] <= 2e-3, (losses, model)
 
 
 @pytest.mark.parametrize("name,hidden,depth", [("grads_64x4_32", 64, 4), ("grads_256x8_32", 256, 8)])
 @pytest.mark.parametrize("dtype,fmt", [("f16", 16), ("f16", 12), ("f16", 8), ("bf16", 16)])
 def test_engine_equals_its_numerics_model(golden, name, hidden, depth, dtype, fmt):
     """Engine vs oracle/engine_model.py (identical rounding points): what remains is fp32 summation
-    order, v_sin/v_cos vs libm, and the occasional rounding tie flipping: <= 2e-3 relative (format 16),
-    <= 3e-3 (format 12: a phase byte that flips moves one sine by up to 2.5e-2; measured 2.4e-3 at 256x8 on 1 280
-    pixels).  Format 8 is held to the model only at depth 4: an fp8 rounding that flips is a 6 % change of that
+    order, v_sin/v_cos vs libm, and the occasional rounding tie flipping: <= 2e-3 relative (fp16, format 16; measured
+    5e-4), <= 3e-3 (bf16, whose 8-bit roundings flip 8x as hard; measured 2.4e-3), <= 4e-3 (format 12: a phase byte
+    that flips moves one sine by up to 2.5e-2; measured 2.9e-3 at 256x8 on 1 280 pixels).  At hidden = 256 layer 0
+    runs on the matrix pipe as a split-fp16 product (k_fwd_pipe, kL0Split): as accurate as the model's fp32 FMAs
+    (6e-7 vs 8e-7 revolutions against float64) but not bit-identical to them, which costs a few more flips than the
+    VALU layer 0 of the other widths (measured with SIREN_FIT_FWD_PIPE=0: 1.7e-3 / 4e-4 / 2.3e-3).  Format 8 is held to the model only at depth 4: an fp8 rounding that flips is a 6 % change of that
     delta, which flips more roundings in the next layer - at depth 8 engine and model decorrelate to the level of the
     fp8 noise itself (measured 2.3e-2, = model vs fp32), which test_forward_and_gradients_vs_reference_golden bounds."""
     from oracle import engine_model as em
@@ -211,7 +216,7 @@ def test_engine_equals_its_numerics_model(golden, name, hidden, depth, dtype, fm
     assert abs(sse_e - sse) <= 1e-4 * sse
     eng.forward_backward()
     g, ref = eng.get_grads().cpu().numpy(), so.flatten(grads)
-    assert _rel(g, ref) <= (2e-3 if fmt == 16 else 3e-3)
+    assert _rel(g, ref) <= (4e-3 if fmt != 16 else 3e-3 if dtype == "bf16" else 2e-3)
 
 
 def test_masks_are_applied_inside_the_step():
