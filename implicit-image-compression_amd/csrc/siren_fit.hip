@@ -225,14 +225,14 @@ int launch_fwd_t(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
 }
 
 // hidden = 256, depth >= 3: the hand-scheduled software pipeline over all layers (k_fwd_pipe)
-int launch_fwd_pipe(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
+int launch_fwd_pipe(sf_engine* h, const FwdArgs& a, int n_wg, bool train) {
   const size_t lds = (size_t)FwdGeom(256).PIECES * 1024 + (size_t)(256 / 32) * 1024 + 64;   // weight image halves + layer-0 image + SSE partials
   const bool f16 = h->cfg.compute_dtype == SF_F16;
 #define SF_FWDP(OP, TR, S8)                                              \
   do {                                                                   \
     int rc = set_lds(k_fwd_pipe<OP, TR, S8>, lds);                       \
     if (rc) return rc;                                                   \
-    hipLaunchKernelGGL((k_fwd_pipe<OP, TR, S8>), dim3(n_super), dim3(512), lds, h->stream, a); \
+    hipLaunchKernelGGL((k_fwd_pipe<OP, TR, S8>), dim3(n_wg), dim3(512), lds, h->stream, a); \
   } while (0)
   if (f16 && train && h->s8) SF_FWDP(OpF16, true, true);
   else if (f16 && train) SF_FWDP(OpF16, true, false);
@@ -399,14 +399,21 @@ int launch_dw_first(sf_engine* h, const Dw0Args& a, int n_wg) {
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
 
+// hidden = 256, depth >= 3 run the persistent pipeline kernel (k_fwd_pipe): one workgroup per CU walks the chunk
+bool fwd_is_pipe(const sf_engine* h) {
+  static const bool no_pipe = getenv("SIREN_FIT_FWD_PIPE") && atoi(getenv("SIREN_FIT_FWD_PIPE")) == 0;   // A/B knob
+  return h->WD == 256 && h->D >= 3 && !no_pipe && !h->wide;
+}
+// forward workgroups of a chunk with n_super 256-pixel groups (= the chunk's SSE partials)
+int fwd_grid(const sf_engine* h, int n_super) { return fwd_is_pipe(h) && n_super > h->dw_wg ? h->dw_wg : n_super; }
+
 int launch_fwd(sf_engine* h, const FwdArgs& a, int n_super, bool train) {
   switch (h->WD) {
     case 32: return launch_fwd_t<32>(h, a, n_super, train);
     case 64: return launch_fwd_t<64>(h, a, n_super, train);
     case 128: return launch_fwd_t<128>(h, a, n_super, train);
     case 256: {
-      static const bool no_pipe = getenv("SIREN_FIT_FWD_PIPE") && atoi(getenv("SIREN_FIT_FWD_PIPE")) == 0;   // A/B knob
-      if (a.depth >= 3 && !no_pipe) return launch_fwd_pipe(h, a, n_super, train);
+      if (fwd_is_pipe(h)) return launch_fwd_pipe(h, a, n_super, train);
       return launch_fwd_t<256>(h, a, n_super, train);
     }
   }
@@ -707,14 +714,17 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
     fa.gscale = h->d8 ? kResScale : (float)((double)h->gpre / ((double)h->cfg.out_features * h->n_total));
     fa.pred = pred;
     fa.sse_part = h->sse_part + sse_off;
+    fa.n_super = n_super;
+    fa.w_magic = ((1ULL << 40) + (unsigned long long)h->cfg.width - 1) / (unsigned long long)h->cfg.width;
+    const int n_fwd_wg = fwd_grid(h, n_super);
 #ifdef SF_EXPERIMENT_STAMP
     fa.dbg = h->sse_part + h->n_sse;   // 64 spare floats behind the partials
 #endif
-    sse_off += n_super;
+    sse_off += n_fwd_wg;
     {
       Launch L(h, K_FWD, flops_fwd_px(h) * n_pb * 32.0,
                n_pb * 32.0 * (4.0 * h->cfg.out_features + (train ? (D - 2) * WD * (h->s8 ? 1.0 : 2.0) + (h->s8 ? 32.0 : 64.0) : 0.0)));
-      rc = launch_fwd(h, fa, n_super, train);
+      rc = launch_fwd(h, fa, n_fwd_wg, train);
       L.done();
       if (rc) return rc;
     }
@@ -751,7 +761,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         ba.inv_hm1 = h->cfg.height > 1 ? 1.0f / (float)(h->cfg.height - 1) : 0.f;
         ba.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
         ba.sc_first = fa.sc_first;
-        ba.sse_part = fa.sse_part; ba.n_part = n_super;
+        ba.sse_part = fa.sse_part; ba.n_part = n_fwd_wg;
         ba.inv_chunk_values = 1.0 / ((double)h->cfg.out_features * (double)px);
         ba.n_values = (double)h->cfg.out_features * h->n_total;
         ba.res_scale = kResScale; ba.target = 8.0f; ba.scale_out = h->scale_dev;
@@ -984,8 +994,8 @@ int sf_destroy(sf_handle* h) {
     hipMemcpy(dbg, h->sse_part + h->n_sse, sizeof(dbg), hipMemcpyDeviceToHost);
     if (h->WD == 256)   // k_fwd_pipe
       for (int i = 0; i < 4; ++i)
-        fprintf(stderr, "k_fwd_pipe stamp wg%d wave%d: entry->layer 0 done %.0f, wait for X1 %.0f, pipeline %.0f (barriers: mid %.0f end %.0f), tail %.0f, total %.0f cycles; entry->table barrier %.0f\n",
-                i >> 1 ? 9000 : 3, i & 1 ? 5 : 0, dbg[i * 8], dbg[i * 8 + 1], dbg[i * 8 + 2], dbg[i * 8 + 3], dbg[i * 8 + 4], dbg[i * 8 + 5], dbg[i * 8 + 6], dbg[i * 8 + 7]);
+        fprintf(stderr, "k_fwd_pipe stamp wg%d wave%d, cycles per 256-pixel group: layer 0 %.0f, wait for X1 %.0f, pipeline %.0f (barriers: mid %.0f end %.0f), %.0f, all %.0f; groups %.0f\n",
+                i >> 1 ? 200 : 3, i & 1 ? 5 : 0, dbg[i * 8], dbg[i * 8 + 1], dbg[i * 8 + 2], dbg[i * 8 + 3], dbg[i * 8 + 4], dbg[i * 8 + 5], dbg[i * 8 + 6], dbg[i * 8 + 7]);
     else
     for (int i = 0; i < 4; ++i)
       fprintf(stderr, "k_fwd stamp wg%d wave%d: hidden-layer loop %.0f cycles, barrier 1 (half X) %.0f, barrier 2 (half Y) %.0f, %d layers\n",

@@ -232,6 +232,8 @@ struct FwdArgs {
   int depth;               // number of Linear layers
   const f32x4* l0tab;      // [WD] {w00, w01, b0, 0}
   const u32x4* l0img;      // k_fwd_pipe: layer 0 as ONE MFMA k-step per 32-neuron tile (WD/32 pieces, see kL0Split)
+  int n_super;             // k_fwd_pipe: 256-pixel groups of this chunk (workgroup w takes groups w, w + gridDim.x, ...)
+  unsigned long long w_magic;   // k_fwd_pipe: ceil(2^40 / W): row = (p * w_magic) >> 40
   const u32x4* wf;         // (depth-2) forward images (FwdImg<WD>::PIECES pieces each, biases included)
   const u32x4* wf_last;    // forward image of the last layer padded to 32 rows + bias piece
   float sc_first;          // first_omega_0 / (2 pi)
@@ -272,11 +274,9 @@ struct FwdImg {
   static __host__ __device__ constexpr int bias_off(int nt) { return (nt < H0 ? nt : nt - H0) * 32; }
 };
 
-// last-layer accumulator -> prediction, residual, dL/dout piece and the workgroup's SSE partial (shared by k_fwd and
-// k_fwd_pipe; called by all 512 threads)
+// last-layer accumulator -> prediction, residual and dL/dout piece of one pixel block; returns this lane's squared residual
 template <typename OP, bool TRAIN, bool S8>
-DEV void fwd_tail(const FwdArgs& a, const f32x16& acc, const float (&tgt)[3], long pix, long pb, bool valid, int lane, int h,
-                  int wave, int tid, float* sRed) {
+DEV float fwd_residual(const FwdArgs& a, const f32x16& acc, const float (&tgt)[3], long pix, long pb, bool valid, int lane, int h) {
   float sse = 0.f;
   float d[3] = {0.f, 0.f, 0.f};
   const float gscale = a.gscale;
@@ -306,7 +306,10 @@ DEV void fwd_tail(const FwdArgs& a, const f32x16& acc, const float (&tgt)[3], lo
     a.Dlast[(pb * 2 + 0) * 64 + lane] = u32x4{OP::pack2(d[0], d[1]), OP::pack2(d[2], 0.f), 0u, 0u};
     a.Dlast[(pb * 2 + 1) * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
   }
-  // workgroup SSE partial (fixed order: lanes by xor-shuffle, then waves 0..7)
+  return sse;
+}
+// workgroup SSE partial (fixed order: lanes by xor-shuffle, then waves 0..7); called by all 512 threads
+DEV void fwd_sse_partial(const FwdArgs& a, float sse, int lane, int wave, int tid, float* sRed) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
   if (lane == 0) sRed[wave] = sse;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(512) void k_fwd(FwdArgs a) {
 #pragma unroll
   for (int s = 0; s < KS; ++s) acc = OP::mfma(sW[s * 64 + lane], B[s], acc);
 
-  fwd_tail<OP, TRAIN, S8>(a, acc, tgt, pix, pb, valid, lane, h, wave, tid, sRed);
+  fwd_sse_partial(a, fwd_residual<OP, TRAIN, S8>(a, acc, tgt, pix, pb, valid, lane, h), lane, wave, tid, sRed);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(512) void k_fwd_pipe(FwdArgs a) {
   static_assert(2 * H0 == NT && PD >= 3 && PD <= 8 && KS == 16, "slot plan: barrier slot KS - PD <= bias slot KS - 4 < store slot KS - 3");
 #ifdef SF_EXPERIMENT_STAMP
   const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
-  unsigned long long st_mid = 0, st_end = 0, st_l0 = 0, st_x1 = 0, st_loop = 0;
+  unsigned long long st_mid = 0, st_end = 0, st_l0 = 0, st_x1 = 0, st_pipe = 0;
 #endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u32x4* sW = reinterpret_cast<u32x4*>(smem);
@@ -574,73 +577,41 @@ __global__ __launch_bounds__(512) void k_fwd_pipe(FwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  auto stage = [&](const u32x4* src, int dst, int n) {
-    for (int pc = wave; pc < n; pc += kWavesFwd) glds16s(src + pc * 64, (uint32_t)lane * 16u, smem + (size_t)(dst + pc) * 1024);
-  };
-  const long pb = (long)blockIdx.x * kWavesFwd + wave;
-  const long pix = a.pix0 + pb * 32 + m;
-  const bool valid = pix < a.npix;
-  const long pc = valid ? pix : a.npix - 1;
-  const int row = (int)(pc / a.W), col = (int)(pc - (long)row * a.W);
-  const float x0 = (a.gh[a.row_begin + row] - 0.5f) * 2.0f;  // siren.py:128
-  const float x1 = (a.gw[col] - 0.5f) * 2.0f;
-  float tgt[3] = {0.f, 0.f, 0.f};
-  if (a.img && h == 0 && valid) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) if (c < a.nout) tgt[c] = a.img[pix * a.nout + c];
-  }
-  asm volatile("" :: "v"(x0), "v"(x1), "v"(tgt[0]), "v"(tgt[1]), "v"(tgt[2]));
   const int L = a.depth - 2;                      // hidden layers (>= 1: the host sends depth 2 to k_fwd)
   glds16s(a.l0img + wave * 64, (uint32_t)lane * 16u, reinterpret_cast<char*>(sL0) + (size_t)wave * 1024);
-  stage(a.wf, 0, IM::X_PIECES);
   asm volatile("" ::: "memory");
-  // B operand of layer 0 (see kL0Split)
-  u32x4 bx = u32x4{0u, 0u, 0u, 0u};
-  {
-    _Float16 x0h, x0l, x1h, x1l;
-    split_f16(x0, kL0Split, x0h, x0l);
-    split_f16(x1, kL0Split, x1h, x1l);
-    const _Float16 x0s = (_Float16)((float)x0h * (1.0f / kL0Split)), x1s = (_Float16)((float)x1h * (1.0f / kL0Split));
-    if (h == 0) bx = u32x4{pack_h2(x0h, x0l), pack_h2(x0s, x1h), pack_h2(x1l, x1s), pack_h2((_Float16)1.0f, (_Float16)(1.0f / kL0Split))};
-  }
-  bar_dma<IM::X_PIECES / kWavesFwd>();   // the layer-0 piece (issued first) landed; the X pieces behind it may stay in flight
-#ifdef SF_EXPERIMENT_STAMP
-  const unsigned long long st_tab = __builtin_amdgcn_s_memtime();
-#endif
+
+  // The workgroup is PERSISTENT: it walks the 256-pixel groups blockIdx.x, blockIdx.x + gridDim.x, ... of the chunk, so
+  // that everything a group needs before its first MFMA overlaps the previous group's pipeline: its coordinates and
+  // target are fetched one group ahead (raw values, five registers), the layer-0 image is staged once, and the SSE is
+  // reduced once at the end.  (One workgroup per group spent 13 % of its life before the first and after the last MFMA,
+  // with nothing else resident on the CU: the LDS holds one weight image.)
+  long pb = 0, pix = 0;                           // pixel block of this wave / pixel of this lane in the current group
+  bool valid = false;
+  struct Fetch { float gh, gw, t[3]; };
+  auto fetch = [&](int grp) -> Fetch {           // raw grid values and target of this lane's pixel in group grp
+    Fetch f{0.f, 0.f, {0.f, 0.f, 0.f}};
+    const long px = a.pix0 + ((long)grp * kWavesFwd + wave) * 32 + m;
+    const bool ok = px < a.npix;
+    const long pcl = ok ? px : a.npix - 1;
+    const unsigned row = (unsigned)(((unsigned long long)pcl * a.w_magic) >> 40);
+    const unsigned col = (unsigned)(pcl - (long)row * a.W);
+    f.gh = a.gh[a.row_begin + (int)row];
+    f.gw = a.gw[col];
+    if (a.img && h == 0 && ok) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) if (c < a.nout) f.t[c] = a.img[px * a.nout + c];
+    }
+    return f;
+  };
+  Fetch nxt_f = fetch((int)blockIdx.x);
+  float sse_acc = 0.f;
+  bar_dma<0>();                                   // layer-0 image staged (and the first group's fetch has landed)
 
   auto slot_end = [&]() {   // nothing moves across: neither memory operations (compiler) nor instructions (scheduler)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  u32x4 Ba[KS], Bb[KS];
-  f32x16 prev, cur;
-  // ---- layer 0: one fp16 MFMA per tile (phases in revolutions), sines of tiles 0..6 -> k-steps 0..13 of Ba; the last
-  // tile is handed to the pipeline as phases in `prev` (its sines are taken by the first slots of layer 1)
-  {
-    auto l0_tile = [&](int nt) {
-      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, sL0[nt * 64 + lane]), __builtin_bit_cast(f16x8, bx),  // (prologue only)
-                                                    f32x16{}, 0, 0, 0);
-    };
-    f32x16 z = l0_tile(0);
-#pragma unroll
-    for (int nt = 1; nt < NT; ++nt) {
-      const f32x16 zn = l0_tile(nt);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        uint32_t w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          w[j] = OP::pack2(__builtin_amdgcn_sinf(z[8 * q + 2 * j]), __builtin_amdgcn_sinf(z[8 * q + 2 * j + 1]));
-          asm volatile("" : "+v"(w[j]));   // pinned to this tile (MachineSink would carry the phases down to their first use)
-        }
-        Ba[2 * (nt - 1) + q] = u32x4{w[0], w[1], w[2], w[3]};
-      }
-      slot_end();
-      z = zn;
-    }
-    prev = z;
-  }
-
   // Explicit LDS addressing: five per-lane base registers, everything else is the 16-bit immediate of the read.  (Left
   // to itself hipcc gave every piece beyond the first 64 KiB its own loop-invariant address register - 56 of them - and
   // spilled what the pipeline needs.)  The empty asm makes a base opaque, so constants are not folded back into it.
@@ -655,7 +626,8 @@ __global__ __launch_bounds__(512) void k_fwd_pipe(FwdArgs a) {
   uint32_t aXb = lds0 + (uint32_t)IM::bias_piece(0) * 1024u + (uint32_t)h * 16u;     // bias piece of half X
   uint32_t aYb = lds0 + (uint32_t)IM::bias_piece(H0) * 1024u + (uint32_t)h * 16u;    // bias piece of half Y
   uint32_t aLb = lds0 + (uint32_t)KS * 1024u + (uint32_t)h * 16u;                    // bias piece of the output layer
-  asm volatile("" : "+v"(aXf), "+v"(aYf), "+v"(aXb), "+v"(aYb), "+v"(aLb));
+  uint32_t aL0 = lds0 + (uint32_t)IM::PIECES * 1024u + lane16;                       // fragments of the layer-0 image
+  asm volatile("" : "+v"(aXf), "+v"(aYf), "+v"(aXb), "+v"(aYb), "+v"(aLb), "+v"(aL0));
   auto frag = [&](int nt, int s2) -> u32x4 {   // fragment (tile, k-step) of the hidden image in LDS
     return nt < H0 ? *(lds_cv4*)(uintptr_t)(aXf + (uint32_t)(nt * KS + s2) * 1024u)
                    : *(lds_cv4*)(uintptr_t)(aYf + (uint32_t)((nt - H0) * KS + s2) * 1024u);
@@ -666,20 +638,51 @@ __global__ __launch_bounds__(512) void k_fwd_pipe(FwdArgs a) {
   };
   auto hidden_bias = [&](int nt) -> uint32_t { return (nt < H0 ? aXb : aYb) + (uint32_t)IM::bias_off(nt) * 4u; };
 
-#ifdef SF_EXPERIMENT_STAMP
-  st_l0 = __builtin_amdgcn_s_memtime();
-#endif
-  bar_dma<0>();                                            // half X of layer 1 landed
-#ifdef SF_EXPERIMENT_STAMP
-  st_x1 = __builtin_amdgcn_s_memtime();
-#endif
+  u32x4 Ba[KS], Bb[KS];
+  f32x16 prev, cur, acc;
   u32x4 fr[PD];                                            // fragments 0..PD-1 of the upcoming tile 0
+  // ---- layer 0 of the current group: one fp16 MFMA per tile (phases in revolutions), sines of tiles 0..6 -> k-steps
+  // 0..13 of Ba; the last tile is handed to the pipeline as phases in `prev` (its sines are taken by the first slots of
+  // layer 1).  Half X of layer 1 is requested on the way, one or two LDS-DMA pieces per tile (everyone left that LDS
+  // region at the barrier in the previous group's output layer).
+  auto layer0 = [&](float x0, float x1) {
+    u32x4 bx = u32x4{0u, 0u, 0u, 0u};      // B operand (see kL0Split)
+    {
+      _Float16 x0h, x0l, x1h, x1l;
+      split_f16(x0, kL0Split, x0h, x0l);
+      split_f16(x1, kL0Split, x1h, x1l);
+      const _Float16 x0s = (_Float16)((float)x0h * (1.0f / kL0Split)), x1s = (_Float16)((float)x1h * (1.0f / kL0Split));
+      if (h == 0) bx = u32x4{pack_h2(x0h, x0l), pack_h2(x0s, x1h), pack_h2(x1l, x1s), pack_h2((_Float16)1.0f, (_Float16)(1.0f / kL0Split))};
+    }
+    auto l0_tile = [&](int nt) {
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, *(lds_cv4*)(uintptr_t)(aL0 + (uint32_t)nt * 1024u)),
+                                                    __builtin_bit_cast(f16x8, bx), f32x16{}, 0, 0, 0);
+    };
+    auto x1_piece = [&](int i) {
+      const int pc = wave + kWavesFwd * i;
+      if (pc < IM::X_PIECES) glds16o(a.wf + (size_t)pc * 64, lane16, lds_wave + (uint32_t)(kWavesFwd * i) * 1024u);
+    };
+    f32x16 z = l0_tile(0);
 #pragma unroll
-  for (int i = 0; i < PD; ++i) fr[i] = frag(0, i);
+    for (int nt = 1; nt < NT; ++nt) {
+      const f32x16 zn = l0_tile(nt);
+      if (nt <= 2) { x1_piece(2 * nt - 2); x1_piece(2 * nt - 1); } else x1_piece(nt + 1);
 #pragma unroll
-  for (int q4 = 0; q4 < 4; ++q4) tile_bias(hidden_bias(0), q4, cur);
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < 2; ++q) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          w[j] = OP::pack2(__builtin_amdgcn_sinf(z[8 * q + 2 * j]), __builtin_amdgcn_sinf(z[8 * q + 2 * j + 1]));
+          asm volatile("" : "+v"(w[j]));   // pinned to this tile (MachineSink would carry the phases down to their first use)
+        }
+        Ba[2 * (nt - 1) + q] = u32x4{w[0], w[1], w[2], w[3]};
+      }
+      slot_end();
+      z = zn;
+    }
+    prev = z;
+  };
+  static_assert(NT + 1 == 9 && 9 * kWavesFwd >= IM::X_PIECES, "layer 0 issues pieces 0..8 of half X");
 
   // epilogue values e of accumulator `acc` -> sines into the two k-steps dst[0], dst[1] and phases into HBM.
   // Slot plan: none in slot 0 (the matrix pipe is still writing acc), two per slot in slots 1..3, one in 4..13.
@@ -798,7 +801,6 @@ __global__ __launch_bounds__(512) void k_fwd_pipe(FwdArgs a) {
     for (int i = 0; i < PD; ++i) fr[i] = ring[NG + i];
   };
   // output layer (one 32-row tile) under the epilogue of the last hidden tile
-  f32x16 acc;
   auto output_layer = [&](u32x4 (&Bi)[KS]) {
     u32x4* ptile = a.P + (size_t)L * a.p_stride + ((size_t)pb * NT + (NT - 1)) * PPT * 64 + lane;
     u32x4 ring[KS + PD];
@@ -808,34 +810,64 @@ __global__ __launch_bounds__(512) void k_fwd_pipe(FwdArgs a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (s + PD < KS) ring[s + PD] = frag(0, s + PD);
+      if (s == KS - PD) bar_lds();     // every read of the output image is issued: the next group may overwrite half X
       cur = OP::mfma(ring[s], Bi[s], cur);
       epi_slot(E, prev, s, &Bi[KS - 2], ptile);
       slot_end();
     }
     acc = cur;
   };
-  // (no exit between the two layers of a pair: the live ring would have to be spilled for it on every iteration)
-  int l = 1;
-  for (; l + 1 <= L; l += 2) {
-    layer(Ba, Bb, l);
-    layer(Bb, Ba, l + 1);
-  }
-  if (l == L) {
-    layer(Ba, Bb, l);
-    output_layer(Bb);
-  } else {
-    output_layer(Ba);
-  }
+  for (int grp = (int)blockIdx.x; grp < a.n_super; grp += (int)gridDim.x) {
+    // this group's coordinates and target (fetched during the previous group)
+    pb = (long)grp * kWavesFwd + wave;
+    pix = a.pix0 + pb * 32 + m;
+    valid = pix < a.npix;
+    const float x0 = (nxt_f.gh - 0.5f) * 2.0f, x1 = (nxt_f.gw - 0.5f) * 2.0f;   // siren.py:128
+    const float tgt[3] = {nxt_f.t[0], nxt_f.t[1], nxt_f.t[2]};
 #ifdef SF_EXPERIMENT_STAMP
-  st_loop = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_g = __builtin_amdgcn_s_memtime();
 #endif
-  fwd_tail<OP, TRAIN, S8>(a, acc, tgt, pix, pb, valid, lane, h, wave, tid, sRed);
+    layer0(x0, x1);
 #ifdef SF_EXPERIMENT_STAMP
-  if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 9000)) {
+    const unsigned long long t_l0 = __builtin_amdgcn_s_memtime();
+    st_l0 += t_l0 - t_g;
+#endif
+    bar_dma<0>();                                            // half X of layer 1 landed
+#ifdef SF_EXPERIMENT_STAMP
+    const unsigned long long t_x1 = __builtin_amdgcn_s_memtime();
+    st_x1 += t_x1 - t_l0;
+#endif
+    if (grp + (int)gridDim.x < a.n_super) nxt_f = fetch(grp + (int)gridDim.x);   // lands under the pipeline
+#pragma unroll
+    for (int i = 0; i < PD; ++i) fr[i] = frag(0, i);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) tile_bias(hidden_bias(0), q4, cur);
+    slot_end();
+    // (no exit between the two layers of a pair: the live ring would have to be spilled for it on every iteration)
+    int l = 1;
+    for (; l + 1 <= L; l += 2) {
+      layer(Ba, Bb, l);
+      layer(Bb, Ba, l + 1);
+    }
+    if (l == L) {
+      layer(Ba, Bb, l);
+      output_layer(Bb);
+    } else {
+      output_layer(Ba);
+    }
+#ifdef SF_EXPERIMENT_STAMP
+    st_pipe += __builtin_amdgcn_s_memtime() - t_x1;
+#endif
+    sse_acc += fwd_residual<OP, TRAIN, S8>(a, acc, tgt, pix, pb, valid, lane, h);
+  }
+  fwd_sse_partial(a, sse_acc, lane, wave, tid, sRed);
+#ifdef SF_EXPERIMENT_STAMP
+  if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 200)) {
     float* o = a.dbg + ((blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 8;
     const unsigned long long st_exit = __builtin_amdgcn_s_memtime();
-    o[0] = (float)(st_l0 - st_entry); o[1] = (float)(st_x1 - st_l0); o[2] = (float)(st_loop - st_x1); o[3] = (float)st_mid;
-    o[4] = (float)st_end; o[5] = (float)(st_exit - st_loop); o[6] = (float)(st_exit - st_entry); o[7] = (float)(st_tab - st_entry);
+    const float ng = (float)((a.n_super - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+    o[0] = (float)st_l0 / ng; o[1] = (float)st_x1 / ng; o[2] = (float)st_pipe / ng; o[3] = (float)st_mid / ng;
+    o[4] = (float)st_end / ng; o[5] = 0.f; o[6] = (float)(st_exit - st_entry) / ng; o[7] = ng;
   }
 #endif
 }
