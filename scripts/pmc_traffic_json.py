@@ -15,7 +15,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_hash  # noqa: E402
 
-NAMES = [("k_fwd<256", "k_fwd"), ("k_bwd<32, 256", "k_bwd_last"), ("k_bwd<256, 256, 2, 4", "k_bwd_hidden"),
+NAMES = [("k_fwd<256", "k_fwd"), ("k_fwd_pipe<", "k_fwd"), ("k_bwd<32, 256", "k_bwd_last"), ("k_bwd<256, 256, 2, 4", "k_bwd_hidden"),
          ("k_bwd<256, 256, 2, 2", "k_bwd_hidden_layer1"), ("k_dw0<256", "k_dw_first"), ("k_dw0_8<256", "k_dw_first"),
          # scratch formats 12 / 8 (siren_s8.hip): LAST, hidden (P0 = false) and layer-1 (P0 = true) forms
          ("k_bwd8<32, 256", "k_bwd_last"), ("k_bwd8<256, 256, 2, 4, false, false", "k_bwd_hidden"),
