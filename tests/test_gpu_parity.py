@@ -100,6 +100,41 @@ def test_ragged_and_tiny_grids(H, W, hidden, depth):
     assert _rel(g, ref) <= 1.5 * _rel(model, ref) + 2e-3
 
 
+@pytest.mark.parametrize("H,W,depth,dtype,fmt,chunk", [
+    (19, 23, 3, "f16", 12, 0),       # one hidden layer: the odd-count tail of the layer loop, output layer on the second buffer
+    (40, 33, 5, "f16", 12, 0),       # three hidden layers: one pair + the odd tail; 1 320 pixels = 5.2 groups of 256
+    (31, 64, 7, "f16", 16, 0),       # five hidden layers, unorm16 phases (two stores per tile epilogue)
+    (48, 50, 4, "bf16", 16, 0),      # even count, bf16 operands (layer 0 stays an fp16 split product)
+    (300, 301, 6, "f16", 12, 32768), # 353 groups in three chunks: more groups than CUs in a chunk, ragged last group, per-chunk partials
+    (64, 64, 8, "f16", 8, 1024),     # fp8 deltas: the chunk scale is formed from the persistent kernel's (fewer) SSE partials
+])
+def test_pipeline_forward_kernel_code_paths(H, W, depth, dtype, fmt, chunk):
+    """k_fwd_pipe (hidden 256, depth >= 3) beyond the 256x8 / 256x6 shapes of the golden fixtures: odd and single hidden
+    layer counts (its layer loop is unrolled by two with a separate tail), group counts that are not a multiple of the
+    persistent grid, several chunks, every scratch format, bf16, and the evaluation form - against the fp32 oracle and the
+    engine's numerics model."""
+    from oracle import engine_model as em
+    p = so.siren_init(256, depth, seed=3)
+    img = so.synthetic_image(H, W, seed=4)
+    grid = so.get_grid(H, W)
+    loss, sse, grads = so.loss_and_grads(p, grid, img)
+    eng = _engine(H, W, 256, depth, dtype, p, img, scratch_format=fmt, chunk_pixels=chunk)
+    pred, sse_e = eng.forward()                                  # evaluation form (no phase stores)
+    tol = 3e-4 if dtype == "f16" else 4e-3
+    assert (pred.cpu() - so.forward(p, grid)).abs().max().item() <= tol
+    assert abs(sse_e - sse) <= (2e-3 if dtype == "f16" else 2e-2) * sse
+    sse_t = eng.forward_backward()                               # training form
+    assert abs(sse_t - sse_e) <= 1e-6 * sse_e                    # same forward, other partial grouping
+    g, ref = eng.get_grads().cpu().numpy(), so.flatten(grads)
+    model = so.flatten(em.loss_and_grads(p, grid, img, fwd=dtype, scratch=fmt)[2])
+    assert _rel(g, ref) <= 1.5 * _rel(model, ref) + (2e-3 if dtype == "f16" else 2e-2)
+    if fmt != 8:                                                 # fp8 roundings decorrelate engine and model with depth
+        assert _rel(g, model) <= (4e-3 if dtype == "f16" else 1.5e-2)
+    g2 = eng.get_grads().clone()
+    eng.forward_backward()
+    assert torch.equal(eng.get_grads(), g2)                      # run-to-run bit-identical
+
+
 @pytest.mark.parametrize("fmt", FORMATS)
 def test_chunking_is_a_summation_order_change_only(fmt):
     """Formats 16 / 12: every stored value is a function of its own pixel, so chunking only reorders fp32 sums.
