@@ -120,9 +120,17 @@ DEV uint32_t phase_byte4(const float* t, const float* after) {
   phase_byte<0>(r, t[0], after[0]); phase_byte<1>(r, t[1], after[1]); phase_byte<2>(r, t[2], after[2]); phase_byte<3>(r, t[3], after[3]);
   return r;
 }
-// decode of byte n: u / 256 revolutions (v_cvt_f32_ubyteN + one multiply)
+// decode of byte n: u / 256 + 2^-16 revolutions (v_cvt_f32_ubyteN + one multiply-add).  The offset (1/256 of the byte
+// step, 1e-4 rad) keeps a decoded phase off the zeros of sin and cos: a neuron whose phase stays within 1/512
+// revolution of 0 for every pixel (no live input) would otherwise have sin = 0 EXACTLY, its outgoing weights an exactly
+// zero gradient, and a topology update that ranks |gradient| (grow.py:86-95) could not tell such a candidate from the
+// zeros it multiplies into the entries that are not candidates (it regrew 767 of 768 weights of a dense last layer).
+#ifndef SF_PHASE_EPS
+#define SF_PHASE_EPS (1.0f / 65536.0f)
+#endif
+constexpr float kPhaseEps = SF_PHASE_EPS;
 template <int BYTE>
-DEV float phase_rev8(uint32_t p) { return (float)((p >> (8 * BYTE)) & 0xffu) * (1.0f / 256.0f); }
+DEV float phase_rev8(uint32_t p) { return __builtin_fmaf((float)((p >> (8 * BYTE)) & 0xffu), 1.0f / 256.0f, kPhaseEps); }
 
 // Delta byte: OCP fp8 e4m3 (3-bit significand, 2^-9 .. 448), SATURATING (the plain conversion returns NaN beyond
 // +-448: isa_probe).  Deltas carry one power-of-two scale per pixel chunk, derived by k_bwd8<LAST> from the chunk's

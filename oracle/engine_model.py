@@ -50,6 +50,9 @@ def _e4m3(x):
     return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
 
 
+PHASE_EPS = 2.0 ** -16     # phase_rev8: a decoded byte phase never sits on a zero of sin / cos (siren_kernels.hip kPhaseEps)
+
+
 def _phase_q8(t):
     """phase byte of k_fwd<.., S8>: low mantissa byte of t + 1.5*2^15 = round-half-even(t * 256) mod 256."""
     return torch.remainder(torch.round(t * 256.0), 256.0)
@@ -90,7 +93,7 @@ def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torc
     grads = [None] * (2 * depth)
     for l in range(L, 0, -1):
         # backward phase decode: u dropped into a float mantissa -> u/65536 revolutions (k_bwd phase_rev_*)
-        ph = ph0 if l - 1 == 0 else q[l - 1] * (1.0 / 65536.0)
+        ph = ph0 if l - 1 == 0 else q[l - 1] * (1.0 / 65536.0) + (PHASE_EPS if scratch == 12 else 0.0)
         act = _rt(torch.sin(TWO_PI * ph.double()).float(), bwd)
         grads[2 * l] = delta.t() @ act
         grads[2 * l + 1] = delta.sum(0)
@@ -137,7 +140,7 @@ def _loss_and_grads_s8(params, grid, img, first_omega_0, hidden_omega_0, n_total
     grads = [None] * (2 * depth)
     delta = dlast
     for l in range(L, 0, -1):
-        ph = ph0 if l - 1 == 0 else q[l - 1] * (1.0 / 256.0)
+        ph = ph0 if l - 1 == 0 else q[l - 1] * (1.0 / 256.0) + PHASE_EPS
         act = _rt(torch.sin(TWO_PI * ph.double()).float(), "f16")
         sc = sc_last if l == L else sc_hidden
         grads[2 * l] = (delta.t() @ act) * sc
