@@ -341,20 +341,14 @@ int launch_bwd8(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) {
     case 64: return last ? launch_bwd8_t<32, 64, 1, 2, true, 8, 8>(h, a, n_wg, p0) : launch_bwd8_t<64, 64, 2, 1, false, 8, 8>(h, a, n_wg, p0);
     case 128: return last ? launch_bwd8_t<32, 128, 1, 4, true, 8, 8>(h, a, n_wg, p0) : launch_bwd8_t<128, 128, 2, 2, false, 8, 8>(h, a, n_wg, p0);
     case 256:
-      // 8 waves (two per SIMD), W^T rows in registers; LDS: 5 + 5 ring slots of 8 KiB, 48 KiB fp16 deltas, 32 KiB fp16
-      // sines = 160 KiB; the P0 variant (no phase ring) takes 8 delta slots
+      // 8 waves (two per SIMD); the ring slots hold the fp8 bytes (8 KiB per block): phase W converts in registers, phase X
+      // reads a 16-bit image expanded once per block (2 x 16 KiB).  Ring depth / parked W^T k-steps: combinations hipcc
+      // allocates without a scratch reload inside the block loop (as for format 12).
+      // hidden: 6 delta slots (48 KiB) + 4 phase slots (32) + X16 (32) + sines (32) + 2 parked k-steps (16) = 160 KiB
+      // layer 1 (P0, no phase ring): 6 delta slots (48) + X16 (32) + sines (32) + 5 parked (40) + layer-0 table = 156 KiB
       if (last) return launch_bwd8_t<32, 256, 1, 8, true, 8, 8>(h, a, n_wg, p0);
-      {
-        static const int waves = [] { const char* e = getenv("SIREN_FIT_BWD8_WAVES"); return e ? atoi(e) : 4; }();   // experiment knob
-        if (waves == 8) return launch_bwd8_t<256, 256, 2, 4, false, 5, 8>(h, a, n_wg, p0);
-        if (waves == 83) return p0 ? launch_bwd8_k<256, 256, 2, 4, false, true, 4, 4>(h, a, n_wg)      // experiment: 8 waves,
-                                   : launch_bwd8_k<256, 256, 2, 4, false, false, 3, 4>(h, a, n_wg);   // 3-slot rings, 4 k-steps parked
-        if (waves == 81) return p0 ? launch_bwd8_k<256, 256, 2, 4, false, true, 6, 2>(h, a, n_wg)         // 8 waves, one / two k-steps of
-                                   : launch_bwd8_k<256, 256, 2, 4, false, false, 5, 1, 4>(h, a, n_wg);   // W^T parked behind a 4-slot phase ring
-        if (waves == 84) return p0 ? launch_bwd8_k<256, 256, 2, 4, false, true, 4, 4>(h, a, n_wg)
-                                   : launch_bwd8_k<256, 256, 2, 4, false, false, 4, 2>(h, a, n_wg);   // 4-slot rings, 2 k-steps parked
-        return launch_bwd8_t<256, 256, 2, 2, false, 5, 8>(h, a, n_wg, p0);
-      }
+      if (p0) return launch_bwd8_k<256, 256, 2, 4, false, true, 6, 5, 0>(h, a, n_wg);
+      return launch_bwd8_k<256, 256, 2, 4, false, false, 6, 2, 4>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }

@@ -62,6 +62,14 @@ struct Bwd8Args {
   float* scale_out;
 };
 
+// operand fragment as it sits in the register ring before the MFMA: 16 bytes of 16-bit floats, or 8 fp8 bytes (IN8)
+template <bool BYTES> struct RawFrag { typedef u32x4 type; };
+template <> struct RawFrag<true> { typedef u32x2 type; };
+DEV u32x4 frag_of(u32x4 r) { return r; }
+DEV u32x4 frag_of(u32x2 r) { return fp8x8_to_f16(r.x, r.y); }
+// row r of an A fragment read with ds_read_b64_tr_b8 through tr8 lane bases = this neuron of the 32-neuron tile
+SF_HOSTDEV int nu8(int r) { return 16 * (r >> 4) + pi_perm((r >> 3) & 1, r & 7); }
+
 template <int JW, int IW, int WAVES_R, int WAVES_C, bool LAST, bool P0, typename OP, int NB, int PARK = 0, int NBP_ = 0, bool D8 = true>
 __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   constexpr int NW = WAVES_R * WAVES_C;
@@ -76,17 +84,25 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   // D8 = false (scratch_format 12): deltas stay 16-bit floats (round-1 F-layout: one piece per k-step) - the ring slot
   // IS the image both products read (X lane-linear at step k, W transposed at step k+1), nothing is converted, and only
   // the phases are bytes.
-  constexpr int DPC = D8 ? (LAST ? 1 : JT) : (LAST ? 2 : KSJ);   // 1 KiB pieces per block in ring D
-  constexpr int DDMA = D8 ? DPC : (LAST ? 1 : KSJ);              // of which the DMA fills (LAST: the second is the zero k-step)
-  constexpr int D16B = D8 ? 3 : 0;                               // fp16 images of the converted byte pieces
+  // D8 = true (scratch_format 8): the deltas a hidden layer READS are fp8 byte pieces (one piece per 32-neuron tile:
+  // byte 8q+j of lane (h,m) = neuron 32 nt + 16 q + PI(h,j)), IN8; the ring slot holds the bytes and both products
+  // read it (fp8 -> fp16 is exact): phase W takes one ds_read_b64_tr_b8 per delta^T fragment and converts in registers (every
+  // wave has its own row tiles: nothing is converted twice); phase X needs every k-step in every wave, so the block is
+  // expanded ONCE, one step ahead, into a 16-bit image (X16, two buffers) that all waves read lane-linearly - converting
+  // in registers there cost 8 x 64 conversions per block instead of 64 and made the kernel VALU-bound.  The LAST layer
+  // reads the 16-bit dL/dout piece k_fwd wrote, exactly as with D8 = false; only what it WRITES is fp8.
+  constexpr bool IN8 = D8 && !LAST;
+  constexpr int DPC = IN8 ? JT : (LAST ? 2 : KSJ);               // 1 KiB pieces per block in ring D
+  constexpr int DDMA = IN8 ? JT : (LAST ? 1 : KSJ);              // of which the DMA fills (LAST: the second is the zero k-step)
+  constexpr int TSTR = IN8 ? 1024 : 2048;                        // bytes of a 32-neuron tile inside a ring slot
   constexpr int PPC = P0 ? 0 : IT;            // 1 KiB pieces per block in ring P
   constexpr int GD = DDMA / NW, GP = PPC / NW; // LDS-DMA instructions EVERY wave issues per block (lower bounds)
   constexpr int S_ST = 2 * XT;                // delta stores per wave per block (one 8-byte half element per k-step of a row tile)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const rD = smem;
   char* const rP = rD + NB * DPC * 1024;
-  char* const d16 = rP + NBP * PPC * 1024;
-  char* const s16 = d16 + D16B * KSJ * 1024;
+  char* const x16 = rP + NBP * PPC * 1024;                       // IN8: two 16-bit images of a block's deltas (B operand of phase X)
+  char* const s16 = x16 + (IN8 ? 2 : 0) * KSJ * 1024;
   char* const wsp0 = s16 + 2 * KSI * 1024;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -116,11 +132,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     for (int i = tid; i < IW; i += NW * 64) dst[i] = a.l0tab[i];
   }
   float dfac = 1.0f;   // LAST: chunk pre-scale / res_scale (power of two)
-  if (LAST && !D8) {   // the zero k-step of dL/dout (padded neurons 16..31) lives in LDS only: second piece of every slot
+  if (LAST) {   // the zero k-step of dL/dout (padded neurons 16..31) lives in LDS only: second piece of every slot
     for (int b = wave; b < NB; b += NW) reinterpret_cast<u32x4*>(rD + (b * DPC + 1) * 1024)[lane] = u32x4{0u, 0u, 0u, 0u};
   }
   if (LAST && D8) {
-    for (int b = wave; b < 3; b += NW) reinterpret_cast<u32x4*>(d16 + (b * KSJ + 1) * 1024)[lane] = u32x4{0u, 0u, 0u, 0u};
     // chunk SSE: thread t sums partials t, t + NW*64, ... in double; threads are combined in index order
     if (D8) {
     double* red = reinterpret_cast<double*>(s16);     // NW*64 doubles <= 4 KiB, free until the first X epilogue
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     const long pb = pb_begin + k * pb_step;
     // (16-bit pieces are read transposed straight from the slot: bank swizzle applied on the SOURCE lane, see sw_lane)
     for (int pc = wave; pc < DDMA; pc += NW)
-      glds16s(a.D + (pb * DDMA + pc) * 64, D8 ? (uint32_t)lane * 16u : ((uint32_t)lsw * 16u) ^ ((uint32_t)(pc & 1) << 7), base + pc * 1024);
+      glds16s(a.D + (pb * DDMA + pc) * 64, IN8 ? (uint32_t)lane * 16u : ((uint32_t)lsw * 16u) ^ ((uint32_t)(pc & 1) << 7), base + pc * 1024);
   };
   auto stageP = [&](int k) {
     if (P0) return;
@@ -173,20 +188,15 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     const long pb = pb_begin + k * pb_step;
     for (int pc = wave; pc < PPC; pc += NW) glds16s(a.P + (pb * IT + pc) * 64, (uint32_t)lane * 16u, base + pc * 1024);
   };
-  // C(k): byte pieces of block k (ring D) -> 16-bit F-layout image D16[k % 3], stored with the bank swizzle the
-  // transposed reads need (slot sw_lane(lane, k-step parity), see sw_lane in siren_kernels.hip)
+  // C(k): byte pieces of block k (ring D) -> 16-bit image X16[k & 1] (lane-linear pieces, one per k-step)
   auto convert = [&](int k) {
-    if (!D8) return;
+    if (!IN8) return;
     const char* src = rD + (k % NB) * DPC * 1024;
-    char* dst = d16 + (k % 3) * KSJ * 1024;
+    char* dst = x16 + (k & 1) * KSJ * 1024;
     for (int pc = wave; pc < DPC; pc += NW) {
       const u32x4 raw = reinterpret_cast<const u32x4*>(src + pc * 1024)[lane];
-      if (LAST) {
-        reinterpret_cast<u32x4*>(dst)[lsw] = raw;
-      } else {
-        reinterpret_cast<u32x4*>(dst + (2 * pc) * 1024)[lsw] = fp8x8_to_f16(raw.x, raw.y);
-        reinterpret_cast<u32x4*>(dst + (2 * pc + 1) * 1024)[lsw ^ 8] = fp8x8_to_f16(raw.z, raw.w);
-      }
+      reinterpret_cast<u32x4*>(dst + (2 * pc) * 1024)[lane] = fp8x8_to_f16(raw.x, raw.y);
+      reinterpret_cast<u32x4*>(dst + (2 * pc + 1) * 1024)[lane] = fp8x8_to_f16(raw.z, raw.w);
     }
   };
   auto pixel_xy = [&](int k, float& x0, float& x1) {
@@ -202,7 +212,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   constexpr int NXB = PF + 1;
   constexpr int ESUB = 8;                       // epilogue slices per row tile: (q, quarter) groups of 2 values
   constexpr bool FB2 = SF_BWD8_FB2 && NW <= 4;  // both pixel k-steps of the activation fragments resident
-  constexpr bool FA2 = SF_BWD8_FA2 || NW <= 4;  // delta^T fragments double-buffered
+#ifndef SF_BWD8_FA2_IN8
+#define SF_BWD8_FA2_IN8 1
+#endif
+  constexpr bool FA2 = SF_BWD8_FA2 || NW <= 4 || (IN8 && SF_BWD8_FA2_IN8);  // delta^T fragments double-buffered
   constexpr int NWC = 2 * WJ;                   // W chunks per step
   constexpr int NE = XT * ESUB;                 // epilogue slices per step
   // ---- LDS addressing --------------------------------------------------------------------------------------
@@ -215,7 +228,13 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   const uint32_t aLN = (uint32_t)lane * 16u;                         // lane-linear piece element
   const uint32_t aT1 = (uint32_t)trb, aT2 = aT1 ^ 64u;               // transposed-read lane bases (half-read 0 / 1)
   const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t oRP = NB * DPC * 1024, oD16 = oRP + NBP * PPC * 1024, oS16 = oD16 + D16B * KSJ * 1024;
+  const uint32_t oRP = NB * DPC * 1024, oX16 = oRP + NBP * PPC * 1024, oS16 = oX16 + (IN8 ? 2 : 0) * KSJ * 1024;
+  // transposed byte reads (IN8): ds_read_b64_tr_b8 works on groups of 16 lanes; lane t of a group supplies the address of
+  // an 8-byte row, result lane i < 8 receives byte i of the rows of lanes 0, 2, .., 14 and lane 8 + i byte i of the rows of
+  // lanes 1, 3, .., 15 (scripts/probes/trb8.hip).  With lane t pointing at bytes 8q .. 8q+7 of piece lane (h' = t & 1,
+  // pixel 8 hq + (t >> 1)) - q = group & 1, hq = group >> 1 - the wave receives an A fragment of the 16-pixel k-step whose
+  // row r = lane & 31 is neuron nu8(r) of the tile and whose elements are the pixels 8 hq + 0..7 in order.
+  const uint32_t aT8 = 16u * (32u * (uint32_t)(lane & 1) + 8u * (uint32_t)(lane >> 5) + (uint32_t)((lane & 15) >> 1)) + 8u * (uint32_t)((lane >> 4) & 1);
   typedef __attribute__((address_space(3))) const u32x4 lds_cv4;
   typedef __attribute__((address_space(3))) u32x4 lds_v4;
   typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
@@ -301,25 +320,34 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   // chunks ahead into a small register ring: with one wave per SIMD (4-wave form) nothing else covers the LDS
   // latency; the 8-wave form has neither the registers nor the need (its SIMD partner fills the gap): PF = 1.
   // W: 2*WJ chunks of WI MFMAs; the VALU epilogue of the X tiles (XT*ESUB slices of 2 values) rides along.
+  typedef typename RawFrag<IN8>::type raw_t;
   auto step = [&](int kx, bool do_c, bool do_x, bool do_w) {
     u32x4 xb[NXB];
-    u32x4 fb[FB2 ? 2 : 1][WI], fa[2];
+    u32x4 fb[FB2 ? 2 : 1][WI];
+    raw_t fa[2];
     f32x16 g[XT];
-    // wave-uniform buffer offsets of this step (SGPRs)
-    // 16-bit image of the deltas of block kx (X) and of block kx-1 (W, this wave's row tiles): the converted copy, or
-    // (D8 = false) the ring slot itself
-    const uint32_t uX = D8 ? smem0 + oD16 + (uint32_t)(kx % 3) * (KSJ * 1024) : smem0 + (uint32_t)(kx % NB) * (DPC * 1024);
-    const uint32_t uWd = (D8 ? smem0 + oD16 + (uint32_t)((kx + 2) % 3) * (KSJ * 1024)
-                             : smem0 + (uint32_t)((kx + NB - 1) % NB) * (DPC * 1024)) + (uint32_t)(wr * WJ) * 2048u;
+    // wave-uniform buffer offsets of this step (SGPRs): ring slots of the deltas of block kx (X) and of block kx-1 (W, this
+    // wave's row tiles)
+    const uint32_t uX = IN8 ? smem0 + oX16 + (uint32_t)(kx & 1) * (KSJ * 1024) : smem0 + (uint32_t)(kx % NB) * (DPC * 1024);
+    const uint32_t uWd = smem0 + (uint32_t)((kx + NB - 1) % NB) * (DPC * 1024) + (uint32_t)(wr * WJ) * (uint32_t)TSTR;
     const uint32_t uWs = smem0 + oS16 + (uint32_t)((kx + 1) & 1) * (KSI * 1024) + (uint32_t)(wc * WI) * 2048u;  // S16 of block kx-1, this wave's column tiles
     const uint32_t uEs = smem0 + oS16 + (uint32_t)(kx & 1) * (KSI * 1024) + (uint32_t)xit0 * 2048u;             // S16 of block kx, this wave's X tiles
     const uint32_t uEp = smem0 + oRP + (uint32_t)(kx % NBP) * (PPC * 1024) + (uint32_t)xit0 * 1024u;             // phase pieces of block kx
     if (do_c) convert(kx + 1);
     if (P0 && do_x) pixel_xy(kx, ep_x0, ep_x1);
-    const uint32_t bX0 = aL1 + uX, bX1 = aL1x + uX;
+    const uint32_t bX0 = (IN8 ? aLN : aL1) + uX, bX1 = (IN8 ? aLN : aL1x) + uX;   // (X16 is stored lane-linearly: no swizzle)
     auto x_load = [&](int c) -> u32x4 { return *(lds_cv4*)(uintptr_t)(((c & 1) ? bX1 : bX0) + c * 1024); };
-    const uint32_t bWa1 = aT1 + uWd, bWa2 = aT2 + uWd, bWb1 = aT1 + uWs, bWb2 = aT2 + uWs;
-    auto wa_load = [&](int kk, int x) -> u32x4 { return tr_pair(bWa1, bWa2, x * 2048 + kk * 256); };
+    const uint32_t bWa1 = (IN8 ? aT8 : aT1) + uWd, bWa2 = aT2 + uWd, bWb1 = aT1 + uWs, bWb2 = aT2 + uWs;
+    // A fragment (delta^T) of row tile x, pixel k-step kk (phase W)
+    auto wa_load = [&](int kk, int x) -> raw_t {
+      if constexpr (IN8) {
+        typedef __attribute__((ext_vector_type(2))) int i32x2;
+        const i32x2 r = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(uintptr_t)(bWa1 + x * TSTR + kk * 256));
+        return u32x2{(uint32_t)r.x, (uint32_t)r.y};
+      } else {
+        return tr_pair(bWa1, bWa2, x * TSTR + kk * 256);
+      }
+    };
     auto wb_load = [&](int kk, u32x4* dst) {
 #pragma unroll
       for (int y = 0; y < WI; ++y) dst[y] = tr_pair(bWb1, bWb2, y * 2048 + kk * 256);
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
             if (x + 1 < WJ) fa[(i + 1) & 1] = wa_load(kk, x + 1);
             else if (kk == 0) fa[(i + 1) & 1] = wa_load(1, 0);
           }
-          w_mma_chunk(x, fa[FA2 ? (i & 1) : 0], fb[FB2 ? kk : 0]);
+          w_mma_chunk(x, frag_of(fa[FA2 ? (i & 1) : 0]), fb[FB2 ? kk : 0]);
           if (!FA2) {   // single fragment buffer: the next one is requested once the MFMAs of this chunk have issued
             if (x + 1 < WJ) fa[0] = wa_load(kk, x + 1);
             else if (kk == 0) fa[0] = wa_load(1, 0);
@@ -387,23 +415,24 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   if (nblk > 0) {
     // Ring protocol.  Step k requests D(k + AD) and P(k + AP); the barrier at the top of step k (B_k) needs D(k + ND)
     // and P(k) landed:
-    //   D8 : AD = NB   (the slot of block k was converted in step k-1),        ND = 1 (C(k+1) runs in step k)
-    //   D16: AD = NB-2 (the slot of block k-2 was last read by W(k-2), step k-1), ND = 0
+    //   D  : AD = NB-2 (the slot of block k-2 was last read by W(k-2), step k-1), ND = 0 - IN8: ND = 1 (C(k+1) runs in step k)
     //   P  : AP = NBP-1 (the slot of block k-1 was decoded in step k-1)
     // so the request B_k waits for was issued AD-ND (resp. AP) steps earlier, and everything issued in the steps after
     // that one is younger in this wave's in-order vmcnt queue: YS = min(AD-ND, AP) - 1 full steps of GD + GP LDS-DMA
     // instructions and S_ST delta stores (full = those steps still had blocks to request).  Outside that steady state
     // the barrier drains the queue.  The first and the last block are peeled: the steady loop body has no conditional
     // phases.
-    constexpr int AD = D8 ? NB : NB - 2, ND = D8 ? 1 : 0, AP = NBP - 1;
+    constexpr int AD = NB - 2, ND = IN8 ? 1 : 0, AP = NBP - 1;
     constexpr int YS = (P0 ? AD - ND : (AD - ND < AP ? AD - ND : AP)) - 1;
     constexpr int AX = P0 ? AD : (AD > AP ? AD : AP);       // a step is full while k + AX < nblk
     static_assert(YS >= 1, "ring depth");
     for (int k = 0; k < AD && k < nblk; ++k) stageD(k);
     for (int k = 0; k < AP && k < nblk; ++k) stageP(k);
     bar_all();                              // prologue only: everything requested so far has landed
-    convert(0);
-    bar_all();
+    if (IN8) {
+      convert(0);
+      bar_all();
+    }
     if (AD < nblk) stageD(AD);
     if (AP < nblk) stageP(AP);
     asm volatile("" ::: "memory");
@@ -430,12 +459,12 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     for (int y = 0; y < WI; ++y)
 #pragma unroll
       for (int t = 0; t < 16; ++t)
-        slab[(size_t)(32 * (wr * WJ + x) + rho(t, hh)) * IW + 32 * (wc * WI + y) + cl] = acc[x][y][t];
+        slab[(size_t)(32 * (wr * WJ + x) + (IN8 ? nu8(rho(t, hh)) : rho(t, hh))) * IW + 32 * (wc * WI + y) + cl] = acc[x][y][t];
   if (wc == 0) {
 #pragma unroll
     for (int x = 0; x < WJ; ++x) {
       const float tsum = dbs[x] + __shfl_xor(dbs[x], 32);
-      if (hh == 0) slab[JW * IW + 32 * (wr * WJ + x) + cl] = tsum;
+      if (hh == 0) slab[JW * IW + 32 * (wr * WJ + x) + (IN8 ? nu8(cl) : cl)] = tsum;
     }
   }
 }
@@ -444,10 +473,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
 template <int JW, int IW, int NW, bool LAST, bool P0, int NB, int PARK = 0, int NBP_ = 0, bool D8 = true>
 constexpr size_t bwd8_lds_bytes() {
   constexpr int JT = JW / 32, IT = IW / 32, KSJ = JW / 16, KSI = IW / 16, KSX = LAST ? 1 : KSJ, XT = IT / NW;
-  constexpr int DPC = D8 ? (LAST ? 1 : JT) : (LAST ? 2 : KSJ), PPC = P0 ? 0 : IT, D16B = D8 ? 3 : 0;
+  constexpr int DPC = (D8 && !LAST) ? JT : (LAST ? 2 : KSJ), PPC = P0 ? 0 : IT;
   constexpr int WSP = PARK;
   constexpr int NBP = NBP_ > 0 ? NBP_ : NB;
-  return (size_t)(NB * DPC + NBP * PPC + D16B * KSJ + 2 * KSI + NW * XT * WSP) * 1024 + (P0 ? (size_t)IW * 16 : 0);
+  return (size_t)(NB * DPC + NBP * PPC + ((D8 && !LAST) ? 2 * KSJ : 0) + 2 * KSI + NW * XT * WSP) * 1024 + (P0 ? (size_t)IW * 16 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------
