@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--scratch", type=int, default=0, choices=[0, 8, 12, 16],
-                    help="sf_config.scratch_format: 0 = auto (12 at hidden <= 256: phase bytes + 16-bit deltas), 8 = phase bytes + fp8 deltas, 16 = round-1 format")
+                    help="sf_config.scratch_format: 0 = auto (hidden <= 256, fp16: 8 = phase bytes + fp8 deltas from 2^20 pixels, 12 = phase bytes + 16-bit deltas below), 16 = round-1 format")
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -222,11 +222,14 @@ def main():
             "metric": f"Mpixel-iters/s (fwd+bwd+Adam) @ SIREN-{args.hidden}x{args.depth}",
             "value": value, "unit": "Mpixel-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if split else "weak",
-            "vs_baseline": None, "dtype": "f16 (fp16 MFMA operands fwd+bwd, f32 accumulate, f32 optimiser state)" if args.dtype == "f16" else "bf16",
+            "vs_baseline": None, "dtype": ("f16 (fp16 MFMA operands fwd+bwd, f32 accumulate, f32 optimiser state; backward scratch in HBM: "
+                      + {8: "phase bytes + fp8 e4m3 deltas", 12: "phase bytes + fp16 deltas", 16: "unorm16 phases + fp16 deltas"}[eng.scratch_format] + ")")
+            if args.dtype == "f16" else "bf16",
             "data": "synthetic",
             "config": {"workload": f"siren_{args.hidden}x{args.depth}_fit_step_{H}x{W}x3_grid", "image": f"{H}x{W}x3",
                        "hidden": args.hidden, "depth": args.depth, "sharding": (f"pixel-split rows x{world} + RCCL grad all-reduce" if split else f"per-image x{world}"),
-                       "chunk_pixels": min(eng.npix, args.chunk or (1 << 22) // max(1, args.hidden // 256))},
+                       "chunk_pixels": min(eng.npix, args.chunk or (1 << 22) // max(1, args.hidden // 256)),
+                       "scratch_format": eng.scratch_format},   # 8 = phase bytes + fp8 deltas, 12 = + 16-bit deltas, 16 = unorm16 / 16-bit
             "step_mfma_frac": value / world * 1e6 * F / (PEAK_BF16_TFLOPS * 1e12),   # per GPU
             "psnr_after_run": psnr,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -100,6 +100,7 @@ struct sf_engine {
   float gpre = 1.f;       // power-of-two pre-scale of dL/dout (fp16 backward operands), undone in k_reduce*
   bool s8 = false;        // phase bytes (scratch_format 8 and 12): k_fwd<.., S8> + the kernels of siren_s8.hip
   bool d8 = false;        // fp8 deltas under a per-chunk adaptive pre-scale (scratch_format 8)
+  bool fmt_auto = false;  // scratch_format was 0 at sf_create: the engine picks it, and moves to 16 when a mask is set
   long d_stride = 0;      // pieces per layer in the delta scratch (p_stride: phases)
   float* scale_dev = nullptr;   // {gpre / n_values_total, 1 / gpre} as the kernels read them (adaptive when s8)
   // data
@@ -847,6 +848,7 @@ extern "C" {
 int sf_abi_version(void) { return SF_ABI_VERSION; }
 const char* sf_last_error(void) { return g_err.c_str(); }
 
+static void set_scratch_strides(sf_engine* h);
 int sf_create(const sf_config* cfg, sf_handle** out) {
   if (!cfg || !out) return fail(SF_ERR_INVALID, "null argument");
   *out = nullptr;
@@ -895,8 +897,13 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   h->WD = cfg->hidden;
   h->wide = cfg->hidden > 256;
   {
+    // auto (fp16 operands, hidden <= 256): phase bytes always; fp8 deltas (format 8) when the image has >= 2^20 pixels - a
+    // gradient then sums the zero-mean fp8 rounding over >= 10^6 terms (within the 0.05 dB criterion on every reference
+    // fixture even at 2^16 pixels) and the backward kernels are bandwidth-bound; smaller fits are
+    // launch-latency-bound and keep 16-bit deltas (format 12).  A masked fit is moved to format 16 by sf_set_masks.
     int fmt = cfg->scratch_format;
-    if (fmt == 0) fmt = (!h->wide && cfg->compute_dtype == SF_F16) ? 12 : 16;
+    h->fmt_auto = fmt == 0;
+    if (fmt == 0) fmt = (h->wide || cfg->compute_dtype != SF_F16) ? 16 : ((double)cfg->height * (double)cfg->width >= 1048576.0 ? 8 : 12);
     h->cfg.scratch_format = fmt;
     h->s8 = fmt == 8 || fmt == 12;
     h->d8 = fmt == 8;
@@ -928,8 +935,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   // layer stride of the scratch tensors, padded so that the three streams a kernel touches at once are
   // not a power of two apart (HBM channel aliasing)
   // (8-bit scratch: one piece per 32-neuron tile instead of one per 16-neuron k-step)
-  h->p_stride = chunk / 32 * (h->s8 ? WD / 32 : WD / 16) * 64 + 37 * 64;
-  h->d_stride = chunk / 32 * (h->d8 ? WD / 32 : WD / 16) * 64 + 37 * 64;
+  set_scratch_strides(h);
 
   h->dw_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("SIREN_FIT_BWD_WGS")) { const int v = atoi(e); if (v >= 8 && v <= h->dw_wg) h->dw_wg = v; }   // experiment knob
@@ -1025,6 +1031,11 @@ int sf_num_params(const sf_handle* h, int64_t* n) {
   *n = h->P;
   return SF_OK;
 }
+int sf_scratch_format(const sf_handle* h, int32_t* format) {
+  if (!h || !format) return fail(SF_ERR_INVALID, "null argument");
+  *format = h->cfg.scratch_format;
+  return SF_OK;
+}
 int sf_param_offset(const sf_handle* h, int32_t layer, int64_t* w, int64_t* b) {
   if (!h || layer < 0 || layer >= h->D) return fail(SF_ERR_INVALID, "bad layer");
   if (w) *w = h->off_w[layer];
@@ -1052,10 +1063,38 @@ int sf_set_params(sf_handle* h, const float* p) {
 int sf_get_params(sf_handle* h, float* p) { return copy_out(h, p, h ? h->params : nullptr); }
 int sf_get_grads(sf_handle* h, float* p) { return copy_out(h, p, h ? h->grads : nullptr); }
 int sf_set_grads(sf_handle* h, const float* p) { return copy_in(h, h ? h->grads : nullptr, p); }
+// layer strides of the phase / delta scratch for the handle's current format
+static void set_scratch_strides(sf_engine* h) {
+  const long chunk = h->chunk_px;
+  const int WD = h->WD;
+  h->p_stride = chunk / 32 * (h->s8 ? WD / 32 : WD / 16) * 64 + 37 * 64;
+  h->d_stride = chunk / 32 * (h->d8 ? WD / 32 : WD / 16) * 64 + 37 * 64;
+}
+// An auto-format handle that receives a mask leaves the 8-bit scratch: fp8 deltas under one scale per chunk underflow in
+// a 90 %-sparse network, and topology updates rank small gradients that phase bytes blur.
+static int switch_scratch_format(sf_engine* h, int fmt) {
+  hipStreamSynchronize(h->stream);
+  if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+  h->cfg.scratch_format = fmt;
+  h->s8 = fmt == 8 || fmt == 12;
+  h->d8 = fmt == 8;
+  set_scratch_strides(h);
+  if (h->Pbuf) hipFree(h->Pbuf);
+  if (h->Dbuf) hipFree(h->Dbuf);
+  h->Pbuf = nullptr; h->Dbuf = nullptr;
+  if (hipMalloc((void**)&h->Pbuf, (size_t)(h->D - 1) * h->p_stride * 16) != hipSuccess ||
+      hipMalloc((void**)&h->Dbuf, (size_t)(h->D - 1) * h->d_stride * 16) != hipSuccess)
+    return fail(SF_ERR_NOMEM, "hipMalloc failed while moving the scratch to format 16");
+  return SF_OK;
+}
 int sf_set_masks(sf_handle* h, const float* p) {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   if (!p) { h->has_mask = false; return SF_OK; }
+  if (h->fmt_auto && !h->wide && h->cfg.scratch_format != 16) {
+    const int rs = switch_scratch_format(h, 16);
+    if (rs) return rs;
+  }
   int rc = copy_in(h, h->mask, p);
   if (!rc) h->has_mask = true;
   return rc;

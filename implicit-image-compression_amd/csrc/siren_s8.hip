@@ -168,6 +168,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   for (int x = 0; x < WJ; ++x)
 #pragma unroll
     for (int y = 0; y < WI; ++y) acc[x][y] = f32x16{};
+#ifndef SF_BWD8_DBSPLIT
+#define SF_BWD8_DBSPLIT 1
+#endif
+  constexpr bool DBSPLIT = IN8 && SF_BWD8_DBSPLIT;   // bias-gradient row sums split over the column waves (IN8 form only: registers)
   float dbs[WJ];
 #pragma unroll
   for (int x = 0; x < WJ; ++x) dbs[x] = 0.f;
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     return s < KSR ? wreg[x][s < KSR ? s : 0]
                    : reinterpret_cast<const u32x4*>(sWsp + (x * WSP + (s >= KSR ? s - KSR : 0)) * 1024)[lane];
   };
+  const float lim448 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x43e00000));   // 448.0f, held in an SGPR
   uint32_t ones_h2 = 0x3c003c00u;   // (1.0h, 1.0h) in a register
   asm volatile("" : "+v"(ones_h2));
   u32x4 ep_d[XT];                   // deltas of one k-step: 8 fp8 (.x .y) or 8 fp16, stored as soon as they are complete
@@ -279,8 +284,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     if (LAST) { c0 *= dfac; c1 *= dfac; }
     if (D8) {
       int w = (int)ep_d[x][v >> 1];
-      w = (v & 1) ? __builtin_amdgcn_cvt_pk_fp8_f32(sat448(g[t0] * c0), sat448(g[t0 + 1] * c1), w, true)
-                  : __builtin_amdgcn_cvt_pk_fp8_f32(sat448(g[t0] * c0), sat448(g[t0 + 1] * c1), 0, false);
+      // saturation as ONE v_med3_f32 per value: both bounds are the same SGPR (the negation is a source modifier), which is
+      // the one constant-bus operand a VOP3 instruction may read
+      const float s0 = __builtin_amdgcn_fmed3f(g[t0] * c0, -lim448, lim448), s1 = __builtin_amdgcn_fmed3f(g[t0 + 1] * c1, -lim448, lim448);
+      w = (v & 1) ? __builtin_amdgcn_cvt_pk_fp8_f32(s0, s1, w, true) : __builtin_amdgcn_cvt_pk_fp8_f32(s0, s1, 0, false);
       ep_d[x][v >> 1] = (uint32_t)w;
     } else {
       ep_d[x][v] = OP::pack2(g[t0] * c0, g[t0 + 1] * c1);
@@ -308,12 +315,14 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     typedef __attribute__((ext_vector_type(2))) _Float16 h2;
     const h2 one2 = __builtin_bit_cast(h2, ones_h2);
     const uint32_t f0 = fa.x, f1 = fa.y, f2 = fa.z, f3 = fa.w;
-    float d = dbs[x];
-    d = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f0), one2, d, false);
-    d = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f1), one2, d, false);
-    d = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f2), one2, d, false);
-    d = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f3), one2, d, false);
-    dbs[x] = d;
+    if (!DBSPLIT || (x % WAVES_C) == wc) {   // DBSPLIT: the WAVES_C waves that hold the same delta^T fragments share the row tiles
+      float d = dbs[x];
+      d = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f0), one2, d, false);
+      d = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f1), one2, d, false);
+      d = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f2), one2, d, false);
+      d = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f3), one2, d, false);
+      dbs[x] = d;
+    }
   };
   // ---- one pipeline step: C(kx+1), X(kx), W(kx-1) in one hand-cut instruction stream -------------------------
   // X: row tile outer; the delta piece of k-step c (lane-linear ds_read_b128 from D16) is the B operand and is read PF
@@ -460,9 +469,9 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
 #pragma unroll
       for (int t = 0; t < 16; ++t)
         slab[(size_t)(32 * (wr * WJ + x) + (IN8 ? nu8(rho(t, hh)) : rho(t, hh))) * IW + 32 * (wc * WI + y) + cl] = acc[x][y][t];
-  if (wc == 0) {
 #pragma unroll
-    for (int x = 0; x < WJ; ++x) {
+  for (int x = 0; x < WJ; ++x) {
+    if (DBSPLIT ? (x % WAVES_C) == wc : wc == 0) {
       const float tsum = dbs[x] + __shfl_xor(dbs[x], 32);
       if (hh == 0) slab[JW * IW + 32 * (wr * WJ + x) + (IN8 ? nu8(cl) : cl)] = tsum;
     }

@@ -50,6 +50,7 @@ def load_library():
         "sf_destroy": [H],
         "sf_abi_version": [],
         "sf_num_params": [H, C.POINTER(I64)],
+        "sf_scratch_format": [H, C.POINTER(C.c_int32)],
         "sf_param_offset": [H, C.c_int32, C.POINTER(I64), C.POINTER(I64)],
         "sf_set_params": [H, F], "sf_get_params": [H, F], "sf_set_masks": [H, F],
         "sf_get_grads": [H, F], "sf_set_grads": [H, F],
@@ -137,6 +138,13 @@ class SirenEngine:
         self.out_features = out_features
         self._target = None
         self._views = {}
+
+    @property
+    def scratch_format(self) -> int:
+        """sf_config.scratch_format in use (what 0 / auto resolved to; an auto handle moves to 16 when a mask is set)"""
+        f = C.c_int32()
+        _check(self.lib.sf_scratch_format(self.h, C.byref(f)))
+        return f.value
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

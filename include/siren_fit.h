@@ -75,7 +75,9 @@ typedef struct sf_config {
                              * 16 = unorm16 phases + 16-bit float deltas (round-1 format);
                              * 12 = phase BYTES + 16-bit float deltas;
                              *  8 = phase bytes + fp8 e4m3 deltas under a per-chunk adaptive power-of-two pre-scale;
-                             *  0 = auto: 12 for hidden <= 256 with SF_F16 (8 and 12 exist only there), else 16      */
+                             *  0 = auto: hidden <= 256 with SF_F16 (8 and 12 exist only there): 8 for images of >= 2^20
+                             *      pixels, 12 below; else 16.  An auto handle moves to 16 when sf_set_masks sets a mask
+                             *      (sparse networks: DESIGN.md section 2)                                             */
 } sf_config;
 
 typedef struct sf_engine sf_handle;
@@ -88,6 +90,7 @@ int sf_abi_version(void);
 
 /* shapes */
 int sf_num_params(const sf_handle* h, int64_t* n_params);          /* P, length of every flat vector */
+int sf_scratch_format(const sf_handle* h, int32_t* format);        /* the format in use (8 / 12 / 16): what 0 resolved to */
 int sf_param_offset(const sf_handle* h, int32_t layer, int64_t* weight_off, int64_t* bias_off);
 
 /* model state: flat fp32 vectors of length P on the device */

@@ -29,7 +29,7 @@ from oracle import siren_oracle as so
 pytestmark = pytest.mark.gpu
 
 
-FORMATS = (16, 12, 8)      # sf_config.scratch_format; 0 / default = 12 for fp16 operands at hidden <= 256
+FORMATS = (16, 12, 8)      # sf_config.scratch_format; 0 / auto (fp16 operands, hidden <= 256) = 8 from 2^20 pixels, 12 below
 
 
 def _rel(a, b):
@@ -133,6 +133,28 @@ def test_pipeline_forward_kernel_code_paths(H, W, depth, dtype, fmt, chunk):
     g2 = eng.get_grads().clone()
     eng.forward_backward()
     assert torch.equal(eng.get_grads(), g2)                      # run-to-run bit-identical
+
+
+def test_auto_scratch_format_rule_and_mask_switch():
+    """sf_config.scratch_format = 0: phase bytes + fp8 deltas from 2^20 pixels, phase bytes + 16-bit deltas below, 16 for
+    bf16 operands and wide layers; an auto handle that receives a mask moves to format 16 (and then equals a handle created
+    with 16 bit for bit), an explicit format stays."""
+    assert _engine(64, 64, 64, 4).scratch_format == 12
+    assert _engine(1024, 1024, 256, 3).scratch_format == 8
+    assert _engine(1023, 1024, 256, 3).scratch_format == 12
+    assert _engine(64, 64, 64, 4, "bf16").scratch_format == 16
+    assert _engine(32, 32, 512, 3).scratch_format == 16
+    H, W, hidden, depth = 48, 40, 128, 5
+    p = so.siren_init(hidden, depth, seed=5)
+    img = so.synthetic_image(H, W, seed=6)
+    gen = torch.Generator().manual_seed(2)
+    flat = torch.cat([((torch.rand(q.shape, generator=gen) < 0.3).float() if q.dim() == 2 else torch.ones_like(q)).reshape(-1) for q in p])
+    auto, fixed16, fixed12 = (_engine(H, W, hidden, depth, "f16", p, img, scratch_format=f) for f in (0, 16, 12))
+    for e in (auto, fixed16, fixed12):
+        e.set_masks(flat.cuda())
+    assert (auto.scratch_format, fixed16.scratch_format, fixed12.scratch_format) == (16, 16, 12)
+    la, lb = auto.step([3e-4] * 5, want_loss=True), fixed16.step([3e-4] * 5, want_loss=True)
+    assert la == lb and torch.equal(auto.get_params(), fixed16.get_params())
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
