@@ -111,6 +111,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   const int xit0 = wave * XT;
   const int trb = tr_lane_base(lane);
   const int lsw = sw_lane(lane, 0);      // slot of this lane's register image in an even 16-bit piece; odd: lsw ^ 8
+  // byte pieces (IN8): slot i of a ring piece holds the element of lane i ^ 8 (i >> 5) - the upper lane half is shifted by
+  // eight pixels, i.e. by 32 banks, so that the even (h' = 0) and odd (h' = 1) row suppliers of a ds_read_b64_tr_b8 group
+  // do not meet on the same banks (2-way conflict on every transposed byte read otherwise)
+  const int lsw8 = lane ^ ((lane >> 5) << 3);
 
   // stationary W^T rows of this wave (as k_bwd): k-steps [0, KSR) in registers, the rest parked in LDS
   // (one wave per SIMD has 512 registers: nothing is parked then)
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     const long pb = pb_begin + k * pb_step;
     // (16-bit pieces are read transposed straight from the slot: bank swizzle applied on the SOURCE lane, see sw_lane)
     for (int pc = wave; pc < DDMA; pc += NW)
-      glds16s(a.D + (pb * DDMA + pc) * 64, IN8 ? (uint32_t)lane * 16u : ((uint32_t)lsw * 16u) ^ ((uint32_t)(pc & 1) << 7), base + pc * 1024);
+      glds16s(a.D + (pb * DDMA + pc) * 64, IN8 ? (uint32_t)lsw8 * 16u : ((uint32_t)lsw * 16u) ^ ((uint32_t)(pc & 1) << 7), base + pc * 1024);
   };
   auto stageP = [&](int k) {
     if (P0) return;
@@ -198,9 +202,9 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     const char* src = rD + (k % NB) * DPC * 1024;
     char* dst = x16 + (k & 1) * KSJ * 1024;
     for (int pc = wave; pc < DPC; pc += NW) {
-      const u32x4 raw = reinterpret_cast<const u32x4*>(src + pc * 1024)[lane];
-      reinterpret_cast<u32x4*>(dst + (2 * pc) * 1024)[lane] = fp8x8_to_f16(raw.x, raw.y);
-      reinterpret_cast<u32x4*>(dst + (2 * pc + 1) * 1024)[lane] = fp8x8_to_f16(raw.z, raw.w);
+      const u32x4 raw = reinterpret_cast<const u32x4*>(src + pc * 1024)[lane];       // element of lane lsw8
+      reinterpret_cast<u32x4*>(dst + (2 * pc) * 1024)[lsw8] = fp8x8_to_f16(raw.x, raw.y);
+      reinterpret_cast<u32x4*>(dst + (2 * pc + 1) * 1024)[lsw8] = fp8x8_to_f16(raw.z, raw.w);
     }
   };
   auto pixel_xy = [&](int k, float& x0, float& x1) {
@@ -238,7 +242,8 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   // lanes 1, 3, .., 15 (scripts/probes/trb8.hip).  With lane t pointing at bytes 8q .. 8q+7 of piece lane (h' = t & 1,
   // pixel 8 hq + (t >> 1)) - q = group & 1, hq = group >> 1 - the wave receives an A fragment of the 16-pixel k-step whose
   // row r = lane & 31 is neuron nu8(r) of the tile and whose elements are the pixels 8 hq + 0..7 in order.
-  const uint32_t aT8 = 16u * (32u * (uint32_t)(lane & 1) + 8u * (uint32_t)(lane >> 5) + (uint32_t)((lane & 15) >> 1)) + 8u * (uint32_t)((lane >> 4) & 1);
+  const uint32_t aT8 = 16u * (32u * (uint32_t)(lane & 1) + ((8u * (uint32_t)(lane >> 5) + (uint32_t)((lane & 15) >> 1)) ^ (8u * (uint32_t)(lane & 1)))) +
+                       8u * (uint32_t)((lane >> 4) & 1);   // (pixel slot ^ 8 h': the lsw8 swizzle of the byte pieces)
   typedef __attribute__((address_space(3))) const u32x4 lds_cv4;
   typedef __attribute__((address_space(3))) u32x4 lds_v4;
   typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
@@ -342,7 +347,14 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     const uint32_t uWs = smem0 + oS16 + (uint32_t)((kx + 1) & 1) * (KSI * 1024) + (uint32_t)(wc * WI) * 2048u;  // S16 of block kx-1, this wave's column tiles
     const uint32_t uEs = smem0 + oS16 + (uint32_t)(kx & 1) * (KSI * 1024) + (uint32_t)xit0 * 2048u;             // S16 of block kx, this wave's X tiles
     const uint32_t uEp = smem0 + oRP + (uint32_t)(kx % NBP) * (PPC * 1024) + (uint32_t)xit0 * 1024u;             // phase pieces of block kx
-    if (do_c) convert(kx + 1);
+    // C(kx+1) rides in the shadow of phase X (sixteen dependent MFMAs with little else to issue): raw bytes read behind
+    // chunk 1, the two converted pieces written behind chunks 6 and 10.  (At the top of the step, with both waves of every
+    // SIMD in it at once, it was a serial LDS round trip.)
+    constexpr bool CVX = IN8 && XT * KSX >= 12 && DPC == NW;
+    if (do_c && !(CVX && do_x)) convert(kx + 1);
+    u32x4 cv_raw;
+    const uint32_t cv_src = smem0 + (uint32_t)((kx + 1) % NB) * (DPC * 1024) + (uint32_t)wave * 1024u + aLN;
+    const uint32_t cv_dst = smem0 + oX16 + (uint32_t)((kx + 1) & 1) * (KSJ * 1024) + (uint32_t)wave * 2048u + (uint32_t)lsw8 * 16u;
     if (P0 && do_x) pixel_xy(kx, ep_x0, ep_x1);
     const uint32_t bX0 = (IN8 ? aLN : aL1) + uX, bX1 = (IN8 ? aLN : aL1x) + uX;   // (X16 is stored lane-linearly: no swizzle)
     auto x_load = [&](int c) -> u32x4 { return *(lds_cv4*)(uintptr_t)(((c & 1) ? bX1 : bX0) + c * 1024); };
@@ -386,6 +398,11 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
             if (FB2) wb_load(1, fb[FB2 ? 1 : 0]);
           }
           g[x] = OP::mfma(w_of(x, c), xb[i % NXB], g[x]);
+          if (CVX && do_c) {
+            if (i == 1) cv_raw = *(lds_cv4*)(uintptr_t)cv_src;
+            if (i == 6) *(lds_v4*)(uintptr_t)cv_dst = fp8x8_to_f16(cv_raw.x, cv_raw.y);
+            if (i == 10) *(lds_v4*)(uintptr_t)(cv_dst + 1024u) = fp8x8_to_f16(cv_raw.z, cv_raw.w);
+          }
           if (PF == 0 && do_w && i + 1 == XT * KSX) {   // no read-ahead: the first W operands follow the last X MFMA
             wb_load(0, fb[0]); fa[0] = wa_load(0, 0);
             if (FB2) wb_load(1, fb[FB2 ? 1 : 0]);
