@@ -347,7 +347,11 @@ int launch_bwd8(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) {
       // allocates without a scratch reload inside the block loop (as for format 12).
       // hidden: 6 delta slots (48 KiB) + 4 phase slots (32) + X16 (32) + sines (32) + 2 parked k-steps (16) = 160 KiB
       // layer 1 (P0, no phase ring): 6 delta slots (48) + X16 (32) + sines (32) + 5 parked (40) + layer-0 table = 156 KiB
-      if (last) return launch_bwd8_t<32, 256, 1, 8, true, 8, 8>(h, a, n_wg, p0);
+      // last layer: 3 MFMAs per block, bound by the latency of a step once its delta output is bytes - rings of 4 slots
+      // (72 KiB) let two workgroups share a CU (2.30 instead of 2.60 ms per step; with 16-bit deltas the kernel is
+      // HBM-bound at 5.4 TB/s and the shallower rings cost 0.3 ms: format 12 keeps one workgroup per CU)
+      if (last) return p0 ? launch_bwd8_t<32, 256, 1, 8, true, 8, 8>(h, a, n_wg, p0)
+                          : launch_bwd8_k<32, 256, 1, 8, true, false, 4, 0, 4>(h, a, n_wg);
       if (p0) return launch_bwd8_k<256, 256, 2, 4, false, true, 6, 5, 0>(h, a, n_wg);
       return launch_bwd8_k<256, 256, 2, 4, false, false, 6, 2, 4>(h, a, n_wg);
   }
@@ -763,9 +767,16 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         const double rows = last ? h->cfg.out_features : WD;
         Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 4.0 * rows * WD * n_pb * 32.0,
                  n_pb * 32.0 * ((last ? 32.0 : WD * (h->d8 ? 1.0 : 2.0)) + WD * (h->d8 ? 1.0 : 2.0) + (p0 ? 0.0 : WD * 1.0)));
-        rc = launch_bwd8(h, last, p0, ba, n_wg);
+        // hidden 256: the last-layer kernel keeps two workgroups per CU (its slab rows are 32 wide: the slab has room)
+        int n_wg_l = n_wg;
+        if (last && !p0 && WD == 256 && h->d8) {
+          n_wg_l = (int)((n_pb + PBS - 1) / PBS);
+          if (n_wg_l > 2 * h->dw_wg) n_wg_l = 2 * h->dw_wg;
+        }
+        rc = launch_bwd8(h, last, p0, ba, n_wg_l);
         L.done();
         if (rc) return rc;
+        ra.n_wg = n_wg_l;
         ra.slab_rows = last ? 32 : WD; ra.slab_cols = WD;
         ra.rows_out = last ? h->cfg.out_features : WD; ra.cols_out = WD; ra.mode = 0;
       } else if (l > 0) {
