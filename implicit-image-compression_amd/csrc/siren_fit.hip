@@ -357,12 +357,16 @@ int launch_bwd8(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) {
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
+// two MFMAs per wave and block behind a workgroup barrier: bound by the latency of a step.  At width 256 a 4-slot ring
+// (64.5 KiB) lets two workgroups share a CU.
+constexpr int dw0_8_ring(int JW) { return JW == 256 ? 4 : 8; }
 template <int JW>
 int launch_dw0_8_t(sf_engine* h, const Dw0Args& a, int n_wg) {
-  const size_t lds = (size_t)(8 * (JW / 32) + 2 * (JW / 16)) * 1024 + 512;   // byte ring + two fp16 images + coordinate table
-  int rc = set_lds(k_dw0_8<JW, OpF16>, lds);
+  constexpr int NB = dw0_8_ring(JW);
+  const size_t lds = (size_t)(NB * (JW / 32) + 2 * (JW / 16)) * 1024 + 512;   // byte ring + two fp16 images + coordinate table
+  int rc = set_lds(k_dw0_8<JW, OpF16, NB>, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_dw0_8<JW, OpF16>), dim3(n_wg), dim3(JW * 2), lds, h->stream, a);
+  hipLaunchKernelGGL((k_dw0_8<JW, OpF16, NB>), dim3(n_wg), dim3(JW * 2), lds, h->stream, a);
   HIPCHK(hipGetLastError());
   return SF_OK;
 }
@@ -813,7 +817,8 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         da.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
         da.w_magic = ((1ULL << 40) + (unsigned long long)h->cfg.width - 1) / (unsigned long long)h->cfg.width;
         Launch L(h, K_DW_FIRST, 4.0 * WD * n_pb * 32.0, WD * (h->d8 ? 1.0 : 2.0) * n_pb * 32.0);
-        int n_wg0 = (int)(n_pb < (long)h->dw_wg ? n_pb : (long)h->dw_wg);
+        const long cap0 = (h->d8 && WD == 256) ? 2L * h->dw_wg : (long)h->dw_wg;      // k_dw0_8<256>: two workgroups per CU
+        int n_wg0 = (int)(n_pb < cap0 ? n_pb : cap0);
         rc = h->d8 ? launch_dw_first8(h, da, n_wg0) : launch_dw_first(h, da, n_wg0);
         L.done();
         if (rc) return rc;

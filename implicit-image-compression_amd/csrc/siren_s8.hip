@@ -509,9 +509,9 @@ constexpr size_t bwd8_lds_bytes() {
 // k_dw0_8: weight gradient of layer 0 from fp8 deltas (k_dw0 of siren_kernels.hip with the byte pieces expanded
 // to the 16-bit image one block ahead).  Ring: 8 slots of JW/32 KiB; D16: 2 x JW/16 KiB.
 // ---------------------------------------------------------------------------------------------
-template <int JW, typename OP>
+template <int JW, typename OP, int NB = 8>
 __global__ __launch_bounds__(JW * 2) void k_dw0_8(Dw0Args a) {
-  constexpr int NW = JW / 32, JT = JW / 32, KSJ = JW / 16, NB = 8;
+  constexpr int NW = JW / 32, JT = JW / 32, KSJ = JW / 16;
   constexpr int GD = JT / NW;   // = 1
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const rD = smem;
