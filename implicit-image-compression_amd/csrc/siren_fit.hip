@@ -768,6 +768,9 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         ba.inv_chunk_values = 1.0 / ((double)h->cfg.out_features * (double)px);
         ba.n_values = (double)h->cfg.out_features * h->n_total;
         ba.res_scale = kResScale; ba.target = 8.0f; ba.scale_out = h->scale_dev;
+#ifdef SF_EXPERIMENT_STAMP
+        ba.dbg = h->sse_part + h->n_sse;
+#endif
         const double rows = last ? h->cfg.out_features : WD;
         Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 4.0 * rows * WD * n_pb * 32.0,
                  n_pb * 32.0 * ((last ? 32.0 : WD * (h->d8 ? 1.0 : 2.0)) + WD * (h->d8 ? 1.0 : 2.0) + (p0 ? 0.0 : WD * 1.0)));
@@ -1006,8 +1009,12 @@ int sf_destroy(sf_handle* h) {
   if (h->stream || true) hipStreamSynchronize(h->stream);
 #ifdef SF_EXPERIMENT_STAMP
   if (!h->wide) {
-    float dbg[32];
+    float dbg[64];
     hipMemcpy(dbg, h->sse_part + h->n_sse, sizeof(dbg), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 8; ++i)
+      if (dbg[32 + i * 4 + 3] > 0)
+        fprintf(stderr, "k_bwd8 %s stamp wg%d wave%d, cycles per block: barrier at the top %.0f, phase X %.0f, phase W + epilogue %.0f (%.0f blocks)\n",
+                i >= 4 ? "layer-1 form" : "hidden form", (i >> 1) & 1 ? 200 : 3, i & 1 ? 5 : 0, dbg[32 + i * 4], dbg[32 + i * 4 + 1], dbg[32 + i * 4 + 2], dbg[32 + i * 4 + 3]);
     if (h->WD == 256)   // k_fwd_pipe
       for (int i = 0; i < 4; ++i)
         fprintf(stderr, "k_fwd_pipe stamp wg%d wave%d, cycles per 256-pixel group: layer 0 %.0f, wait for X1 %.0f, pipeline %.0f (barriers: mid %.0f end %.0f), %.0f, all %.0f; groups %.0f\n",

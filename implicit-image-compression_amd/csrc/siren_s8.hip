@@ -60,6 +60,7 @@ struct Bwd8Args {
   double n_values;             // out_features * H * W of the full image
   float res_scale, target;
   float* scale_out;
+  float* dbg;                  // SF_EXPERIMENT_STAMP builds only
 };
 
 // operand fragment as it sits in the register ring before the MFMA: 16 bytes of 16-bit floats, or 8 fp8 bytes (IN8)
@@ -335,7 +336,13 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   // latency; the 8-wave form has neither the registers nor the need (its SIMD partner fills the gap): PF = 1.
   // W: 2*WJ chunks of WI MFMAs; the VALU epilogue of the X tiles (XT*ESUB slices of 2 values) rides along.
   typedef typename RawFrag<IN8>::type raw_t;
+#ifdef SF_EXPERIMENT_STAMP
+  unsigned long long st_bar = 0, st_x = 0, st_w = 0, st_n = 0;
+#endif
   auto step = [&](int kx, bool do_c, bool do_x, bool do_w) {
+#ifdef SF_EXPERIMENT_STAMP
+    const unsigned long long t_s0 = __builtin_amdgcn_s_memtime();
+#endif
     u32x4 xb[NXB];
     u32x4 fb[FB2 ? 2 : 1][WI];
     raw_t fa[2];
@@ -411,6 +418,9 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
         }
       }
     }
+#ifdef SF_EXPERIMENT_STAMP
+    const unsigned long long t_s1 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -436,6 +446,10 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#ifdef SF_EXPERIMENT_STAMP
+    const unsigned long long t_s2 = __builtin_amdgcn_s_memtime();
+    if (do_x && do_w) { st_x += t_s1 - t_s0; st_w += t_s2 - t_s1; st_n += 1; }
+#endif
   };
 
   if (nblk > 0) {
@@ -464,7 +478,13 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     asm volatile("" ::: "memory");
     if (nblk > 1) step(0, true, true, false); else step(0, false, true, false);
     for (int k = 1; k + 1 < nblk; ++k) {
+#ifdef SF_EXPERIMENT_STAMP
+      const unsigned long long t_b0 = __builtin_amdgcn_s_memtime();
+#endif
       if (k >= YS && k - 1 + AX < nblk) bar_dma<YS * (GD + GP + S_ST)>(); else bar_all();
+#ifdef SF_EXPERIMENT_STAMP
+      st_bar += __builtin_amdgcn_s_memtime() - t_b0;
+#endif
       if (k + AD < nblk) stageD(k + AD);
       if (k + AP < nblk) stageP(k + AP);
       asm volatile("" ::: "memory");
@@ -477,6 +497,12 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     bar_lds();
     step(nblk, false, false, true);
   }
+#ifdef SF_EXPERIMENT_STAMP
+  if (a.dbg && !LAST && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 200) && st_n) {
+    float* o = a.dbg + 32 + ((blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 4 + (P0 ? 16 : 0);
+    o[0] = (float)st_bar / (float)st_n; o[1] = (float)st_x / (float)st_n; o[2] = (float)st_w / (float)st_n; o[3] = (float)st_n;
+  }
+#endif
   float* slab = a.slab + (size_t)blockIdx.x * (JW * IW + JW);
   const int cl = lane & 31, hh = lane >> 5;
 #pragma unroll
