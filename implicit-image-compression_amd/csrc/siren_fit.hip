@@ -325,13 +325,8 @@ int launch_bwd12(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) 
       if (last) return launch_bwd12_t<32, 256, 1, 8, true, 8>(h, a, n_wg, p0);
       // hidden: 5 delta slots (80 KiB) + 4 phase slots (32) + sines (32) + 2 parked k-steps (16) = 160 KiB
       // layer 1 (P0, no phase ring): 5 delta slots + sines + 4 parked k-steps + layer-0 table = 148 KiB
-      {
-        static const int var = [] { const char* e = getenv("SIREN_FIT_BWD12_VARIANT"); return e ? atoi(e) : 0; }();   // experiment knob
-        if (p0) return launch_bwd8_k<256, 256, 2, 4, false, true, 5, 4, 0, false>(h, a, n_wg);
-        if (var == 1) return launch_bwd8_k<256, 256, 2, 4, false, false, 6, 0, 4, false>(h, a, n_wg);   // 6 delta slots, nothing parked
-        if (var == 2) return launch_bwd8_k<256, 256, 2, 4, false, false, 6, 1, 3, false>(h, a, n_wg);   // 6 delta + 3 phase slots, 1 parked
-        return launch_bwd8_k<256, 256, 2, 4, false, false, 5, 2, 4, false>(h, a, n_wg);
-      }
+      if (p0) return launch_bwd8_k<256, 256, 2, 4, false, true, 5, 4, 0, false>(h, a, n_wg);
+      return launch_bwd8_k<256, 256, 2, 4, false, false, 5, 2, 4, false>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
