@@ -323,10 +323,10 @@ int launch_bwd12(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) 
     case 128: return last ? launch_bwd12_t<32, 128, 1, 4, true, 8>(h, a, n_wg, p0) : launch_bwd12_t<128, 128, 2, 2, false, 8>(h, a, n_wg, p0);
     case 256:
       if (last) return launch_bwd12_t<32, 256, 1, 8, true, 8>(h, a, n_wg, p0);
-      // hidden: 5 delta slots (80 KiB) + 4 phase slots (32) + sines (32) + 2 parked k-steps (16) = 160 KiB
+      // hidden: 5 delta slots (80 KiB) + 3 phase slots (24) + sines (32) + 2 parked k-steps (16) + sin/cos table (1) = 153 KiB
       // layer 1 (P0, no phase ring): 5 delta slots + sines + 4 parked k-steps + layer-0 table = 148 KiB
       if (p0) return launch_bwd8_k<256, 256, 2, 4, false, true, 5, 4, 0, false>(h, a, n_wg);
-      return launch_bwd8_k<256, 256, 2, 4, false, false, 5, 2, 4, false>(h, a, n_wg);
+      return launch_bwd8_k<256, 256, 2, 4, false, false, 5, 2, 3, false>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
@@ -340,7 +340,7 @@ int launch_bwd8(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) {
       // 8 waves (two per SIMD); the ring slots hold the fp8 bytes (8 KiB per block): phase W converts in registers, phase X
       // reads a 16-bit image expanded once per block (2 x 16 KiB).  Ring depth / parked W^T k-steps: combinations hipcc
       // allocates without a scratch reload inside the block loop (as for format 12).
-      // hidden: 6 delta slots (48 KiB) + 4 phase slots (32) + X16 (32) + sines (32) + 2 parked k-steps (16) = 160 KiB
+      // hidden: 5 delta slots (40 KiB) + 4 phase slots (32) + X16 (32) + sines (32) + 2 parked k-steps (16) + sin/cos table (1) = 153 KiB
       // layer 1 (P0, no phase ring): 6 delta slots (48) + X16 (32) + sines (32) + 5 parked (40) + layer-0 table = 156 KiB
       // last layer: 3 MFMAs per block, bound by the latency of a step once its delta output is bytes - rings of 4 slots
       // (72 KiB) let two workgroups share a CU (2.30 instead of 2.60 ms per step; with 16-bit deltas the kernel is
@@ -348,7 +348,7 @@ int launch_bwd8(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) {
       if (last) return p0 ? launch_bwd8_t<32, 256, 1, 8, true, 8, 8>(h, a, n_wg, p0)
                           : launch_bwd8_k<32, 256, 1, 8, true, false, 4, 0, 4>(h, a, n_wg);
       if (p0) return launch_bwd8_k<256, 256, 2, 4, false, true, 6, 5, 0>(h, a, n_wg);
-      return launch_bwd8_k<256, 256, 2, 4, false, false, 6, 2, 4>(h, a, n_wg);
+      return launch_bwd8_k<256, 256, 2, 4, false, false, 5, 2, 4>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }

@@ -131,6 +131,21 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     for (int s = KSR; s < KSX; ++s)
       reinterpret_cast<u32x4*>(sWsp + (x * WSP + s - KSR) * 1024)[lane] = a.wb[((xit0 + x) * KSX + s) * 64 + lane];
   }
+#ifndef SF_BWD8_TAB
+#define SF_BWD8_TAB 1
+#endif
+  // A phase byte has 256 values: sin and cos of its decoded phase come from a 1 KiB table in LDS (one ds_read_b32 per value:
+  // the pair as two 16-bit floats) instead of v_cvt_f32_ubyte + v_fma + v_sin + v_cos per value - the X epilogue is what
+  // bounds phase W (VALU issue of two waves per SIMD).  The sine is the value the table-free form wrote to S16 bit for bit;
+  // the cosine is rounded to 16 bits before it meets the accumulator (whose product is rounded to 8 or 16 bits anyway).
+  constexpr bool TAB = SF_BWD8_TAB && !P0 && std::is_same<OP, OpF16>::value;
+  uint32_t* const sTab = reinterpret_cast<uint32_t*>(wsp0 + (size_t)NW * XT * WSP * 1024);
+  if (TAB) {
+    for (int i = tid; i < 256; i += NW * 64) {
+      const float r = __builtin_fmaf((float)i, 1.0f / 256.0f, kPhaseEps);
+      sTab[i] = OP::pack2(__builtin_amdgcn_sinf(r), __builtin_amdgcn_cosf(r));
+    }
+  }
   const f32x4* sL0 = reinterpret_cast<const f32x4*>(wsp0 + (size_t)NW * XT * WSP * 1024);
   if (P0) {
     f32x4* dst = reinterpret_cast<f32x4*>(wsp0 + (size_t)NW * XT * WSP * 1024);
@@ -237,6 +252,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   const uint32_t aLN = (uint32_t)lane * 16u;                         // lane-linear piece element
   const uint32_t aT1 = (uint32_t)trb, aT2 = aT1 ^ 64u;               // transposed-read lane bases (half-read 0 / 1)
   const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t aTab = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)((NB * DPC + NBP * PPC + (IN8 ? 2 : 0) * KSJ + 2 * KSI + NW * XT * WSP) * 1024);
   const uint32_t oRP = NB * DPC * 1024, oX16 = oRP + NBP * PPC * 1024, oS16 = oX16 + (IN8 ? 2 : 0) * KSJ * 1024;
   // transposed byte reads (IN8): ds_read_b64_tr_b8 works on groups of 16 lanes; lane t of a group supplies the address of
   // an 8-byte row, result lane i < 8 receives byte i of the rows of lanes 0, 2, .., 14 and lane 8 + i byte i of the rows of
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
   auto x_epi_sub = [&](int k, int x, int e, const f32x16& g, uint32_t bP, uint32_t bS, uint32_t bSx) {
     // e = 4*q + v: values 2v, 2v+1 of k-step 2*it+q (bytes 8q + 2v, 8q + 2v + 1 of the tile's 16-byte piece element)
     const int q = e >> 2, v = e & 3, it = xit0 + x, ks = 2 * it + q;
-    float r0, r1;
+    float r0 = 0.f, r1 = 0.f;
     if (P0) {
       const f32x4 ta = sL0[16 * ks + pi_perm(lane >> 5, 2 * v)], tb = sL0[16 * ks + pi_perm(lane >> 5, 2 * v + 1)];
       r0 = __builtin_fmaf(ta.y, ep_x1, __builtin_fmaf(ta.x, ep_x0, ta.z)) * a.sc_first;
@@ -281,12 +297,28 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
       // 8 phase bytes of k-step q in one 8-byte read per 4 slices (a dword per 2 slices is a 4-way bank conflict at
       // the 16-byte lane stride of a piece; 8 bytes are 2-way)
       if (v == 0) ep_pw2 = *(__attribute__((address_space(3))) const u32x2*)(uintptr_t)(bP + x * 1024 + 8 * q);
-      const uint32_t pw = (v >> 1) ? ep_pw2.y : ep_pw2.x;
-      if (v & 1) { r0 = phase_rev8<2>(pw); r1 = phase_rev8<3>(pw); }
-      else { r0 = phase_rev8<0>(pw); r1 = phase_rev8<1>(pw); }
+      if constexpr (!TAB) {
+        const uint32_t pw = (v >> 1) ? ep_pw2.y : ep_pw2.x;
+        if (v & 1) { r0 = phase_rev8<2>(pw); r1 = phase_rev8<3>(pw); }
+        else { r0 = phase_rev8<0>(pw); r1 = phase_rev8<1>(pw); }
+      }
     }
     const int t0 = 8 * q + 2 * v;
-    float c0 = __builtin_amdgcn_cosf(r0), c1 = __builtin_amdgcn_cosf(r1);
+    float c0, c1;
+    uint32_t sn;
+    if constexpr (TAB) {
+      typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+      const uint32_t pw = (v >> 1) ? ep_pw2.y : ep_pw2.x;
+      const int b0 = (v & 1) ? 2 : 0;
+      const uint32_t e0 = *(lds_cu32*)(uintptr_t)(aTab + (((pw >> (8 * b0)) & 0xffu) << 2));
+      const uint32_t e1 = *(lds_cu32*)(uintptr_t)(aTab + (((pw >> (8 * b0 + 8)) & 0xffu) << 2));
+      c0 = (float)__builtin_bit_cast(h2, e0)[1];
+      c1 = (float)__builtin_bit_cast(h2, e1)[1];
+      sn = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // (sin 0, sin 1)
+    } else {
+      c0 = __builtin_amdgcn_cosf(r0); c1 = __builtin_amdgcn_cosf(r1);
+      sn = OP::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
+    }
     if (LAST) { c0 *= dfac; c1 *= dfac; }
     if (D8) {
       int w = (int)ep_d[x][v >> 1];
@@ -299,7 +331,6 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
       ep_d[x][v] = OP::pack2(g[t0] * c0, g[t0 + 1] * c1);
     }
     // sines of two slices (4 values) leave in one 8-byte write
-    const uint32_t sn = OP::pack2(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));
     if ((v & 1) == 0) ep_sn = sn;
     else *(__attribute__((address_space(3))) u32x2*)(uintptr_t)((q ? bSx : bS) + x * 2048 + q * 1024 + 4 * (v - 1)) = u32x2{ep_sn, sn};
     if (v == 3) {   // bytes 8q .. 8q+7 of this lane's piece element
@@ -528,7 +559,7 @@ constexpr size_t bwd8_lds_bytes() {
   constexpr int DPC = (D8 && !LAST) ? JT : (LAST ? 2 : KSJ), PPC = P0 ? 0 : IT;
   constexpr int WSP = PARK;
   constexpr int NBP = NBP_ > 0 ? NBP_ : NB;
-  return (size_t)(NB * DPC + NBP * PPC + ((D8 && !LAST) ? 2 * KSJ : 0) + 2 * KSI + NW * XT * WSP) * 1024 + (P0 ? (size_t)IW * 16 : 0);
+  return (size_t)(NB * DPC + NBP * PPC + ((D8 && !LAST) ? 2 * KSJ : 0) + 2 * KSI + NW * XT * WSP) * 1024 + (P0 ? (size_t)IW * 16 : 1024);   // P0: layer-0 table; else the sin/cos table of the phase bytes
 }
 
 // ---------------------------------------------------------------------------------------------
