@@ -52,7 +52,10 @@ def plateau(th, siren, data, size, steps=200, lr_step=40):
     img = synthetic_image(size, size)
     grid = data.get_grid(size, size)
     out = {}
-    for threads in (8, 2):
+    # the second thread count only measures the reference's own summation-order spread; PLATEAU_THREADS=8,4 for large sizes
+    # (a 2-thread run of the 512 x 512 fixture takes an hour)
+    t_a, t_b = (int(t) for t in os.environ.get("PLATEAU_THREADS", "8,2").split(","))
+    for threads in (t_a, t_b):
         torch.set_num_threads(threads)
         torch.manual_seed(0)
         m = siren.Siren(depth=8, hidden_size=256, **MLP)
@@ -64,7 +67,7 @@ def plateau(th, siren, data, size, steps=200, lr_step=40):
         out[threads] = (init, np.array(losses, np.float64), psnr, psnr8, flat_params(m))
         print(f"plateau_256x8_{size}: threads {threads} psnr {psnr:.4f} psnr8 {psnr8:.4f} loss[-1] {losses[-1]:.3e}", flush=True)
     torch.set_num_threads(8)
-    a, b = out[8], out[2]
+    a, b = out[t_a], out[t_b]
     # (the seed-0 init is not stored: oracle.siren_init reproduces it bit for bit, pinned by init_head / init_sha256)
     np.savez_compressed(f"{OUT}/plateau_256x8_{size}.npz", init_head=a[0][:64], init_sha256=sha(a[0]), losses=a[1],
                         psnr=a[2], psnr8=a[3], psnr_2threads=b[2], psnr_spread=abs(a[2] - b[2]), steps=steps,
