@@ -55,7 +55,7 @@ def plateau(th, siren, data, size, steps=200, lr_step=40):
     # the second thread count only measures the reference's own summation-order spread; PLATEAU_THREADS=8,4 for large sizes
     # (a 2-thread run of the 512 x 512 fixture takes an hour)
     t_a, t_b = (int(t) for t in os.environ.get("PLATEAU_THREADS", "8,2").split(","))
-    for threads in (t_a, t_b):
+    for threads in ((t_a,) if t_a == t_b else (t_a, t_b)):    # PLATEAU_THREADS=8,8: one run (the 1024 x 1024 fixture: 70 minutes)
         torch.set_num_threads(threads)
         torch.manual_seed(0)
         m = siren.Siren(depth=8, hidden_size=256, **MLP)
