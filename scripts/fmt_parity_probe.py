@@ -1,5 +1,5 @@
-"""PSNR deviation from the real reference's fixtures per scratch format: config 1 (64x4, 256x256, 1000 steps, un-annealed:
-chaotic to +-0.15 dB under any perturbation) and the 256x8 plateau fixture (annealed, the parity criterion's home)."""
+"""PSNR deviation from the real reference's config-1 fixture (64x4, 256x256, 1000 steps, un-annealed: chaotic to +-0.15 dB
+under any perturbation) per scratch format; the annealed plateau fixtures are asserted in tests/test_gpu_parity.py."""
 import math, os, sys, numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, os.path.join(R, "implicit-image-compression_amd"))
@@ -13,6 +13,4 @@ for fmt in (16, 12, 8):
     eng.step([so.step_lr(3e-4, t) for t in range(1000)])
     _, sse = eng.forward(want_pred=False)
     c1 = 10 * math.log10(3 * H * W / sse) - float(d["psnr"])
-    d = np.load(os.path.join(R, "tests/golden/plateau_256x8_256.npz"))
-    S = int(d["size"]); img = so.synthetic_image(S, S, noise=0.05) if "noise" in so.synthetic_image.__code__.co_varnames else so.synthetic_image(S, S)
     print(f"format {fmt}: config-1 dPSNR {c1:+.4f} dB")
