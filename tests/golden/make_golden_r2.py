@@ -9,6 +9,8 @@ inert stubs for the absent non-arithmetic imports, models/siren.py loaded by pat
                           here and passed through train_epoch's own lr_scheduler argument, train_helper.py:183-184; the
                           reference's default StepLR(2000, .5) would leave a 200-step run mid-spike).  Run twice, with
                           8 and with 2 torch threads: `psnr_spread` is the reference's own summation-order noise.
+                          Committed sizes: S = 256 (default), 512 (PLATEAU_SIZE=512 PLATEAU_THREADS=8,4: 45 minutes) and
+                          1024 (PLATEAU_SIZE=1024 PLATEAU_THREADS=8,8: one run, 70 minutes, ~25 GB of autograd state).
   shapes_{W}x{D}.npz      BASELINE config 3 shapes (256x6, 512x6, 512x8) on a ragged 24x40 image: first-step loss,
                           prediction and dense gradients + a 10-step loss curve.
   rigl_256x8_48.npz       BASELINE config 4 at its real shape: SIREN 256x8, RigL density 0.1 (ERK), 160 steps on a
