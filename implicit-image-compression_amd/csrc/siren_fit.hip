@@ -7,6 +7,7 @@
 // for the full-batch grid (implicit_image/compress.py:137-138).
 #include "siren_kernels.hip"
 #include "siren_s8.hip"
+#include "siren_s8h.hip"
 #include "siren_wide.hip"
 
 #include <math.h>
@@ -330,6 +331,21 @@ int launch_bwd12(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) 
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
+#ifndef SF_BWD8H_PARK
+#define SF_BWD8H_PARK 3
+#endif
+#ifndef SF_BWD8H_NBP
+#define SF_BWD8H_NBP 3
+#endif
+int launch_bwd8h(sf_engine* h, const Bwd8Args& a, int n_wg) {
+  constexpr size_t lds = bwd8h_lds_bytes<SF_BWD8H_PARK, SF_BWD8H_NBP>();
+  static_assert(lds <= 160 * 1024, "k_bwd8h LDS budget");
+  int rc = set_lds(k_bwd8h<SF_BWD8H_PARK, SF_BWD8H_NBP>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_bwd8h<SF_BWD8H_PARK, SF_BWD8H_NBP>), dim3(n_wg), dim3(512), lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
 int launch_bwd8(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) {
   if (!h->d8) return launch_bwd12(h, last, p0, a, n_wg);
   switch (h->WD) {
@@ -348,6 +364,10 @@ int launch_bwd8(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) {
       if (last) return p0 ? launch_bwd8_t<32, 256, 1, 8, true, 8, 8>(h, a, n_wg, p0)
                           : launch_bwd8_k<32, 256, 1, 8, true, false, 4, 0, 4>(h, a, n_wg);
       if (p0) return launch_bwd8_k<256, 256, 2, 4, false, true, 6, 5, 0>(h, a, n_wg);
+      {   // hidden layers: the slot-per-MFMA pipeline (siren_s8h.hip); SIREN_FIT_BWD8H=0 selects the round-2 kernel (A/B knob)
+        static const bool old_form = getenv("SIREN_FIT_BWD8H") && atoi(getenv("SIREN_FIT_BWD8H")) == 0;
+        if (!old_form) return launch_bwd8h(h, a, n_wg);
+      }
       return launch_bwd8_k<256, 256, 2, 4, false, false, 5, 2, 4>(h, a, n_wg);
   }
   return fail(SF_ERR_INVALID, "unsupported hidden width");

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Round-3 golden vectors, minted by running the REAL reference in this container (recipe of make_golden.py: inert stubs
+for the absent non-arithmetic imports, models/siren.py loaded by path; only DATA is written, the images are regenerated
+from oracle.siren_oracle formulas on the test side and pinned by a sha256).
+
+    python tests/golden/make_golden_r3.py [nonsmooth] [long] [config1] [horizon] [kmeans] [truncate512]
+
+  plateau_ns_256x8_{S}.npz  the metric model (SIREN 256x8) on the S x S NON-SMOOTH image (oracle.nonsmooth_image: step edges,
+                            regions clamped at 0 and 1, a one-pixel checkerboard, 0.1 % outlier pixels): 200 full-batch steps
+                            of the reference's train_epoch, Adam lr 3e-4, StepLR(40, 0.5).  8 and 2 torch threads: the
+                            reference's own summation-order spread is stored (NS_SIZE / NS_THREADS select other sizes).
+  long_64x4_256.npz         the reference's REAL schedule - get_optimizer_lr_scheduler's StepLR(2000, 0.5)
+  long_128x6_128.npz        (train_helper.py:80-84) - over 4000 steps (64x4 on the 256 x 256, 128x6 on the 128 x 128 non-smooth
+                            image): loss curve, end PSNR, mean loss of the last 200 steps; 8 and 2 threads.
+  hot_64x4_256_spread.npz   BASELINE config 1 (hot_64x4_256.npz: 1000 un-annealed steps) re-run with 8 and with 2 threads:
+                            the reference's own end-PSNR spread on that run.
+  hot_64x4_256_annealed.npz config 1 annealed (StepLR(200, 0.5), 1000 steps): the settled value the 0.05 dB criterion is
+                            meaningful on; 8 and 2 threads.
+  horizon_256x8_64.npz      long horizon / small residual: SIREN 256x8 on the 64 x 64 non-smooth image, 3000 steps,
+                            StepLR(500, 0.5): PSNR far above the 31 dB of the plateau fixtures; 8 and 2 threads.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from make_golden import Cfg, flat_params, import_reference, sha, synthetic_image  # noqa: E402
+from oracle.siren_oracle import nonsmooth_image  # noqa: E402  (image formula only; nothing of the oracle's arithmetic)
+
+OUT = HERE
+MLP = dict(name="siren", first_omega_0=50, hidden_omega_0=30, outermost_linear=True, simulate_quantization=False)
+
+
+def fit(th, siren, grid, img, hidden, depth, steps, threads, lr_step=None):
+    """`steps` train_epochs of the reference; lr_step None = the reference's own scheduler (StepLR(2000, .5))."""
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = siren.Siren(depth=depth, hidden_size=hidden, **MLP)
+    init = flat_params(m)
+    optim, sched = th.get_optimizer_lr_scheduler(m, Cfg(name="adam", lr=3e-4))
+    if lr_step is not None:
+        sched = torch.optim.lr_scheduler.StepLR(optim, lr_step, gamma=0.5)
+    losses = []
+    for i in range(steps):
+        losses.append(th.train_epoch(m, optim, grid, img, lr_scheduler=sched))
+        if (i + 1) % 500 == 0:
+            print(f"    step {i + 1}: loss {losses[-1]:.4e}", flush=True)
+    _, l, psnr, psnr8 = th.eval_epoch(m, grid, img)
+    torch.set_num_threads(8)
+    return dict(init=init, losses=np.array(losses, np.float64), psnr=psnr, psnr8=psnr8, final=flat_params(m))
+
+
+def two_runs(th, siren, grid, img, hidden, depth, steps, lr_step, name, threads=(8, 2), extra=None):
+    r = {}
+    for t in threads:
+        r[t] = fit(th, siren, grid, img, hidden, depth, steps, t, lr_step)
+        print(f"{name}: threads {t} psnr {r[t]['psnr']:.4f} psnr8 {r[t]['psnr8']:.4f} loss[-1] {r[t]['losses'][-1]:.4e}", flush=True)
+    a, b = r[threads[0]], r[threads[-1]]
+    tail = min(200, steps)
+    rec = dict(init_head=a["init"][:64], init_sha256=sha(a["init"]), losses=a["losses"], psnr=a["psnr"], psnr8=a["psnr8"],
+               psnr_2threads=b["psnr"], psnr_spread=abs(a["psnr"] - b["psnr"]),
+               tail_loss=float(a["losses"][-tail:].mean()), tail_loss_2threads=float(b["losses"][-tail:].mean()),
+               losses_2threads=b["losses"], steps=steps, lr_step=-1 if lr_step is None else lr_step,
+               final_head=a["final"][:4096], img_sha256=sha(img.numpy()), height=img.shape[0], width=img.shape[1],
+               hidden=hidden, depth=depth, threads=np.array(threads))
+    if extra:
+        rec.update(extra)
+    np.savez_compressed(f"{OUT}/{name}.npz", **rec)
+    print(f"{name}: spread {rec['psnr_spread']:.4f} dB, tail loss {rec['tail_loss']:.4e} / {rec['tail_loss_2threads']:.4e}", flush=True)
+    return rec
+
+
+def main():
+    what = sys.argv[1:] or ["config1", "horizon", "long", "nonsmooth"]
+    torch.set_num_threads(8)
+    th, siren, data, _ = import_reference()
+    if "config1" in what:
+        img, grid = synthetic_image(256, 256), data.get_grid(256, 256)
+        old = np.load(f"{OUT}/hot_64x4_256.npz")
+        r = {t: fit(th, siren, grid, img, 64, 4, 1000, t) for t in (8, 2)}
+        assert np.array_equal(r[8]["init"], old["init"])
+        np.savez_compressed(f"{OUT}/hot_64x4_256_spread.npz", psnr_8threads=r[8]["psnr"], psnr_2threads=r[2]["psnr"],
+                            psnr_spread=abs(r[8]["psnr"] - r[2]["psnr"]), psnr_fixture=float(old["psnr"]),
+                            losses_8threads=r[8]["losses"], losses_2threads=r[2]["losses"])
+        print(f"config 1 un-annealed: 8 threads {r[8]['psnr']:.4f}, 2 threads {r[2]['psnr']:.4f}, fixture {float(old['psnr']):.4f}", flush=True)
+        two_runs(th, siren, grid, img, 64, 4, 1000, 200, "hot_64x4_256_annealed")
+    if "horizon" in what:
+        img, grid = nonsmooth_image(64, 64), data.get_grid(64, 64)
+        two_runs(th, siren, grid, img, 256, 8, 3000, 500, "horizon_256x8_64")
+    if "long" in what:
+        img, grid = nonsmooth_image(256, 256), data.get_grid(256, 256)
+        two_runs(th, siren, grid, img, 64, 4, 4000, None, "long_64x4_256")
+        img, grid = nonsmooth_image(128, 128), data.get_grid(128, 128)
+        two_runs(th, siren, grid, img, 128, 6, 4000, None, "long_128x6_128")
+    if "nonsmooth" in what:
+        S = int(os.environ.get("NS_SIZE", "256"))
+        threads = tuple(int(t) for t in os.environ.get("NS_THREADS", "8,2").split(","))
+        img, grid = nonsmooth_image(S, S), data.get_grid(S, S)
+        two_runs(th, siren, grid, img, 256, 8, 200, 40, f"plateau_ns_256x8_{S}", threads=threads)
+
+
+if __name__ == "__main__":
+    main()
