@@ -103,6 +103,7 @@ struct sf_engine {
   bool d8 = false;        // fp8 deltas under a per-chunk adaptive pre-scale (scratch_format 8)
   bool fmt_auto = false;  // scratch_format was 0 at sf_create: the engine picks it, and moves to 16 when a mask is set
   long d_stride = 0;      // pieces per layer in the delta scratch (p_stride: phases)
+  char* pad8 = nullptr;         // k_bwd8h: 1 KiB of zeros, then (at +8 KiB) an 8 KiB dump
   float* scale_dev = nullptr;   // {gpre / n_values_total, 1 / gpre} as the kernels read them (adaptive when s8)
   // data
   float *gh = nullptr, *gw = nullptr;
@@ -783,6 +784,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         ba.inv_chunk_values = 1.0 / ((double)h->cfg.out_features * (double)px);
         ba.n_values = (double)h->cfg.out_features * h->n_total;
         ba.res_scale = kResScale; ba.target = 8.0f; ba.scale_out = h->scale_dev;
+        ba.zeros = reinterpret_cast<const u32x4*>(h->pad8); ba.dump = reinterpret_cast<u32x4*>(h->pad8 + 8192);
 #ifdef SF_EXPERIMENT_STAMP
         ba.dbg = h->sse_part + h->n_sse;
 #endif
@@ -1000,7 +1002,8 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
   { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4 + 4096); }
   h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
-  ALLOC(h->sse_part, (h->n_sse + 64) * 4); ALLOC(h->sse_dev, 8); ALLOC(h->scale_dev, 16);
+  ALLOC(h->sse_part, (h->n_sse + 64) * 4); ALLOC(h->sse_dev, 8); ALLOC(h->scale_dev, 16); ALLOC(h->pad8, 16384);
+  if (!rc && hipMemset(h->pad8, 0, 16384) != hipSuccess) rc = fail(SF_ERR_NOMEM, "hipMemset failed");
 #undef ALLOC
   if (rc) { sf_destroy(h); return rc; }
   {
@@ -1030,6 +1033,15 @@ int sf_destroy(sf_handle* h) {
       if (dbg[32 + i * 4 + 3] > 0)
         fprintf(stderr, "k_bwd8 %s stamp wg%d wave%d, cycles per block: barrier at the top %.0f, phase X %.0f, phase W + epilogue %.0f (%.0f blocks)\n",
                 i >= 4 ? "layer-1 form" : "hidden form", (i >> 1) & 1 ? 200 : 3, i & 1 ? 5 : 0, dbg[32 + i * 4], dbg[32 + i * 4 + 1], dbg[32 + i * 4 + 2], dbg[32 + i * 4 + 3]);
+#ifdef SF_EXPERIMENT_STAMP2
+    for (int w = 0; w < 2; ++w) {
+      fprintf(stderr, "k_bwd8h slot stamps wg3 wave%d: X slots", w ? 5 : 0);
+      for (int i = 0; i < 16; ++i) fprintf(stderr, " %.0f", dbg[w * 32 + i]);
+      fprintf(stderr, " | W+E slots");
+      for (int i = 16; i < 32; ++i) fprintf(stderr, " %.0f", dbg[w * 32 + i]);
+      fprintf(stderr, "\n");
+    }
+#else
     if (h->WD == 256)   // k_fwd_pipe
       for (int i = 0; i < 4; ++i)
         fprintf(stderr, "k_fwd_pipe stamp wg%d wave%d, cycles per 256-pixel group: layer 0 %.0f, wait for X1 %.0f, pipeline %.0f (barriers: mid %.0f end %.0f), %.0f, all %.0f; groups %.0f\n",
@@ -1038,6 +1050,7 @@ int sf_destroy(sf_handle* h) {
     for (int i = 0; i < 4; ++i)
       fprintf(stderr, "k_fwd stamp wg%d wave%d: hidden-layer loop %.0f cycles, barrier 1 (half X) %.0f, barrier 2 (half Y) %.0f, %d layers\n",
               i >> 1 ? 9000 : 3, i & 1 ? 5 : 0, dbg[i * 4], dbg[i * 4 + 1], dbg[i * 4 + 2], (int)dbg[i * 4 + 3]);
+#endif
   }
   if (h->wide) {
     unsigned long long dbg[32];
@@ -1054,7 +1067,7 @@ int sf_destroy(sf_handle* h) {
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab, h->l0img,
                   h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part, h->biasw, h->Abuf,
-                  h->sse_dev, h->scale_dev};
+                  h->sse_dev, h->scale_dev, h->pad8};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->gexec) hipGraphExecDestroy(h->gexec);
   if (h->gstream) { hipStreamSynchronize(h->gstream); hipStreamDestroy(h->gstream); hipEventDestroy(h->gev_in); hipEventDestroy(h->gev_out); }

@@ -61,6 +61,8 @@ struct Bwd8Args {
   float res_scale, target;
   float* scale_out;
   float* dbg;                  // SF_EXPERIMENT_STAMP builds only
+  const u32x4* zeros;          // k_bwd8h: 1 KiB of zeros (delta pieces beyond the last block)
+  u32x4* dump;                 // k_bwd8h: 8 KiB nobody reads (deltas of the blocks beyond the last)
 };
 
 // operand fragment as it sits in the register ring before the MFMA: 16 bytes of 16-bit floats, or 8 fp8 bytes (IN8)
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(WAVES_R* WAVES_C * 64) void k_bwd8(Bwd8Args a) {
     bar_lds();
     step(nblk, false, false, true);
   }
-#ifdef SF_EXPERIMENT_STAMP
+#if defined(SF_EXPERIMENT_STAMP) && !defined(SF_EXPERIMENT_STAMP2)
   if (a.dbg && !LAST && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 200) && st_n) {
     float* o = a.dbg + 32 + ((blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 4 + (P0 ? 16 : 0);
     o[0] = (float)st_bar / (float)st_n; o[1] = (float)st_x / (float)st_n; o[2] = (float)st_w / (float)st_n; o[3] = (float)st_n;

@@ -46,7 +46,8 @@ template <int PARK, int NBP>
 constexpr size_t bwd8h_lds_bytes() { return (size_t)(1 + 3 * 8 + NBP * 8 + 3 * 16 + 2 * 16 + 8 * PARK) * 1024; }
 
 // DBX: the row tile (0..3) whose bias-gradient sums this instantiation takes (= the wave's column index wc)
-template <int PARK, int NBP, int DBX>
+// ROLE: 0 = waves 0-3 ("N": X | W + E), 1 = waves 4-7 ("S", their SIMD partners: W + E | X)
+template <int PARK, int NBP, int DBX, int ROLE>
 __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, const int lane) {
   typedef OpF16 OP;
   constexpr int KS = 16, NT = 8, NBD = 3, WJ = 4, WI = 2;
@@ -98,16 +99,15 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   const int nblk = (int)((a.n_pb - pb_begin + pb_step - 1) / pb_step);
 
   // LDS-DMA of this wave's piece of a block: deltas (tile `wave` of the 8 byte pieces) / phase bytes.  A request beyond the
-  // last block re-reads the last one into a slot nobody reads any more: every step issues the same vector-memory
-  // operations, so one counted vmcnt serves every barrier and the step has no conditional parts.
-  auto stageD = [&](int k, uint32_t slot) {
-    const int ks = k < nblk ? k : nblk - 1;
-    glds16o(a.D + ((pb_begin + (long)ks * pb_step) * NT + wave) * 64, aLN, oRD + slot * 8192u + (uint32_t)wave * 1024u);
-  };
-  auto stageP = [&](int k, uint32_t slot) {
-    const int ks = k < nblk ? k : nblk - 1;
-    glds16o(a.P + ((pb_begin + (long)ks * pb_step) * NT + wave) * 64, aLN, oRP + slot * 8192u + (uint32_t)wave * 1024u);
-  };
+  // last block reads 1 KiB of zeros (deltas) or the last block again (phase bytes): every step issues the same
+  // vector-memory operations, so one counted vmcnt serves every barrier and the step has no conditional parts.
+  // (the global addresses are carried from step to step - one scalar add and one select per request, no multiplies)
+  const long blk_stride = pb_step * NT * 64;                       // u32x4 elements from a block of this workgroup to its next
+  const u32x4* const pD0 = a.D + (pb_begin * NT + wave) * 64;
+  const u32x4* const pP0 = a.P + (pb_begin * NT + wave) * 64;
+  u32x4* const pO0 = a.Dout + (pb_begin * NT + wave) * 64;
+  auto stageD = [&](const u32x4* src, uint32_t slot) { glds16o(src, aLN, oRD + slot * 8192u + (uint32_t)wave * 1024u); };
+  auto stageP = [&](const u32x4* src, uint32_t slot) { glds16o(src, aLN, oRP + slot * 8192u + (uint32_t)wave * 1024u); };
   auto slot_end = [&]() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -119,145 +119,229 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
     return u32x4{a0.x, a0.y, a1.x, a1.y};
   };
 
-  // ---- one pipeline step: [DMA requests] C(kx+1) | X(kx) | W(kx-1) + E(kx), 32 slots ------------------------------
+#ifdef SF_EXPERIMENT_STAMP
+  unsigned long long st_bar = 0, st_x = 0, st_w = 0, st_n = 0;
+#endif
+#ifdef SF_EXPERIMENT_STAMP2
+  unsigned st2[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) st2[i] = 0u;
+  unsigned st2_n = 0;
+#endif
+  // ---- the two phases of a block, 16 slots each -----------------------------------------------------------------------
+  //   phase X(k)            16 MFMAs of the data-gradient product (one dependent chain), B pieces from X16(k)
+  //   phase W(kw) + E(ke)   16 MFMAs of the weight-gradient product of block kw beside the sixteen epilogue values of block
+  //                         ke (cos * g -> fp8, sines -> S16(ke)); ke is the block whose phase X this wave ran last
+  // THE TWO WAVES OF A SIMD RUN OPPOSITE PHASES (a stagger of half a block).  Waves 0-3 ("N") run X(k) | W(k-1)+E(k) in the
+  // two halves of step k; their SIMD partners, waves 4-7 ("S"), run W(k-2)+E(k-1) | X(k).  Run in step, both waves of a
+  // SIMD were in the LDS-bound chain of phase X (all eight waves stream the same 16 KiB of deltas) and then both in the
+  // VALU-heavy phase W: the younger wave took 1 550-1 900 cycles for a phase X whose MFMAs need 1 024 per SIMD while the
+  // older one waited 800-1 000 cycles at the barrier.  Staggered, a phase X always runs beside a phase W: LDS, VALU and the
+  // matrix pipe see the same mix in every half.  Price: a second workgroup barrier per block (each half is closed by one),
+  // and E(k) of the S waves crosses a barrier (g, the phase bytes and the first table pairs stay in registers).
+  //   who needs what, with h = 2k (first half of step k) and h = 2k + 1 (second half):
+  //     X16(k+1)  written at h = 2k+1 by every wave (C(k+1), from the byte ring) - read by X(k+1) at h = 2k+2 (N), 2k+3 (S)
+  //               and by W(k+1) at h = 2k+5 (N), 2k+6 (S); its buffer is rewritten at h = 2k+7: three buffers
+  //     S16(k)    written at h = 2k+1 (N waves' tiles) and 2k+2 (S waves' tiles) - read at h = 2k+3 (N), 2k+4 (S); rewritten
+  //               at h = 2k+5: two buffers
+  //     D(k+3)    requested at h = 2k into the ring slot C(k) emptied at h = 2k-1;  P(k+AP) requested at h = 2k+1 into the
+  //               slot whose bytes were last read at h = 2k-1 (S waves' E(k-1) reads them at the end of X(k-1))
   u32x4 fa[2];
   u32x4 fb[2][WI];
-  // i3 = kx mod 3, ip = kx mod NBP: carried by the caller (a modulo by a non-power of two is a dozen scalar instructions)
-  auto step = [&](int kx, uint32_t i3, uint32_t ip) __attribute__((always_inline)) {
-    constexpr bool do_c = true, do_x = true, do_w = true, dma_p = true, dma_d = true;   // (every step is the full step)
-    const uint32_t i3n = i3 == 2u ? 0u : i3 + 1u, i3p = i3 == 0u ? 2u : i3 - 1u, i2 = (uint32_t)(kx & 1);
-    const uint32_t ipp = ip == 0u ? (uint32_t)(NBP - 1) : ip - 1u;      // slot of block kx - 1 = slot of block kx + AP
-    const uint32_t uX = oX16 + i3 * 16384u;                                           // X(kx): B operand
-    const uint32_t uC = oX16 + i3n * 16384u + (uint32_t)wave * 2048u;                 // C(kx+1): destination (k-steps 2 wave, 2 wave + 1)
-    const uint32_t uCs = oRD + i3n * 8192u + (uint32_t)wave * 1024u;                  // C(kx+1): byte piece
-    const uint32_t uWd = oX16 + i3p * 16384u + (uint32_t)(wr * WJ) * 2048u;           // W(kx-1): delta^T tiles of this wave's row group
-    const uint32_t uWs = oS16 + (i2 ^ 1u) * 16384u + (uint32_t)(wc * WI) * 2048u;     // W(kx-1): sine tiles of this wave's column group
-    const uint32_t uEs = oS16 + i2 * 16384u + (uint32_t)wave * 2048u;                 // E(kx): sines of this wave's tile
-    const uint32_t uEp = oRP + ip * 8192u + (uint32_t)wave * 1024u; // E(kx): phase bytes of this wave's tile
-    // Per-step base registers = lane pattern + wave-uniform offset, formed where they are first needed and made opaque
-    // (empty asm): a ds_* instruction takes one address register + a 16-bit immediate, and hipcc folds every constant it
-    // can see into a 32-bit literal of a separate v_add per access otherwise (the LDS offsets here exceed 16 bits).
-    auto base = [&](uint32_t lane_part, uint32_t uni) -> uint32_t {
-      uint32_t b = lane_part + uni;
-      asm volatile("" : "+v"(b));
-      return b;
-    };
-    uint32_t bX0 = 0, bX1 = 0, bWa1 = 0, bWa2 = 0, bWb1 = 0, bWb2 = 0, bS = 0, bSx = 0;
-    auto x_load = [&](int c) -> u32x4 { return *(lds_cv4*)(uintptr_t)(((c & 1) ? bX1 : bX0) + (uint32_t)c * 1024u); };
-    auto wa_load = [&](int kk, int x) -> u32x4 { return tr_pair(bWa1, bWa2, x * 2048 + kk * 256); };
-    auto wb_load = [&](int kk, u32x4* dst) {
+  f32x16 g = f32x16{};
+  u32x4 pw = {0u, 0u, 0u, 0u};
+  uint32_t tab[NTAB];
 #pragma unroll
-      for (int y = 0; y < WI; ++y) dst[y] = tr_pair(bWb1, bWb2, y * 2048 + kk * 256);
-    };
+  for (int i = 0; i < NTAB; ++i) tab[i] = 0u;
+  // Per-step base registers = lane pattern + wave-uniform offset, formed where they are first needed and made opaque
+  // (empty asm): a ds_* instruction takes one address register + a 16-bit immediate, and hipcc folds every constant it
+  // can see into a 32-bit literal of a separate v_add per access otherwise (the LDS offsets here exceed 16 bits).
+  auto base = [&](uint32_t lane_part, uint32_t uni) -> uint32_t {
+    uint32_t b = lane_part + uni;
+    asm volatile("" : "+v"(b));
+    return b;
+  };
+  // phase-byte u of value t -> table address 4 u (the table starts at LDS address 0)
+  auto lookup = [&](int t) -> uint32_t {
+    const uint32_t w = pw[t >> 2];
+    const uint32_t adr = (t & 3) == 3 ? (w >> 24) << 2 : (((w >> (8 * (t & 3))) & 0xffu) << 2);
+#ifdef SF_EXP_NOLOOKUP     // timing-only: no table read
+    return adr | 0x3c000000u;
+#endif
+    return *(lds_cu32*)(uintptr_t)adr;
+  };
+  struct WOps { uint32_t a1, a2, b1, b2; };      // base registers of the operand fragments of a phase W
+  auto wa_load = [&](const WOps& o, int kk, int x) -> u32x4 { return tr_pair(o.a1, o.a2, x * 2048 + kk * 256); };
+  auto wb_load = [&](const WOps& o, int kk, u32x4* dst) {
+#pragma unroll
+    for (int y = 0; y < WI; ++y) dst[y] = tr_pair(o.b1, o.b2, y * 2048 + kk * 256);
+  };
+  // byte offsets of the operand images of W(b): delta^T tiles of this wave's row group in X16(b), sine tiles of its column
+  // group in S16(b)
+  auto w_uni_d = [&](uint32_t x16buf) -> uint32_t { return oX16 + x16buf * 16384u + (uint32_t)(wr * WJ) * 2048u; };
+  auto w_uni_s = [&](uint32_t s16buf) -> uint32_t { return oS16 + s16buf * 16384u + (uint32_t)(wc * WI) * 2048u; };
+
+  // X(k): xbuf = X16 buffer of block k.  cvt: C(k+1) rides along (byte slot / X16 buffer cbuf).  dma: 0 none, 1 = D(k+3)
+  // into ring slot dslot, 2 = P(k+AP) into ring slot dslot.  pslot: ring slot of the phase bytes of block k (read for the
+  // epilogue that follows).  pre: the operand fragments of the NEXT phase W of this wave are requested at the end
+  // (S waves: both images are complete; N waves: only the delta^T image is).
+  auto phaseX = [&](uint32_t xbuf, bool cvt, uint32_t cbuf, int dma, const u32x4* dsrc, uint32_t dslot, uint32_t pslot, int pre, uint32_t wdbuf, uint32_t wsbuf, WOps& wo) __attribute__((always_inline)) {
+    const uint32_t uX = oX16 + xbuf * 16384u;
+    const uint32_t uC = oX16 + cbuf * 16384u + (uint32_t)wave * 2048u;                 // C: destination (k-steps 2 wave, 2 wave + 1)
+    const uint32_t uCs = oRD + cbuf * 8192u + (uint32_t)wave * 1024u;                  // C: byte piece
+    const uint32_t uEp = oRP + pslot * 8192u + (uint32_t)wave * 1024u;
+    const uint32_t bX0 = base(aL1, uX), bX1 = base(aL1x, uX);
+    auto x_load = [&](int c) -> u32x4 { return *(lds_cv4*)(uintptr_t)(((c & 1) ? bX1 : bX0) + (uint32_t)c * 1024u); };
     u32x4 xb[NXB];
     u32x4 wt[PARK > 0 ? PARK : 1];
-    u32x4 cv_raw = {0u, 0u, 0u, 0u}, pw = {0u, 0u, 0u, 0u}, ep_d = {0u, 0u, 0u, 0u};
-    uint32_t tab[NTAB];
-    uint32_t ep_sn = 0;
-    float sv_even = 0.f;
-    f32x16 g = f32x16{};
-    if (do_x) {
-      bX0 = base(aL1, uX); bX1 = base(aL1x, uX);
+    u32x4 cv_raw = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int c = 0; c < PF; ++c) xb[c] = x_load(c);
-    }
+    for (int c = 0; c < PF; ++c) xb[c] = x_load(c);
     slot_end();
-    // phase-byte u of value t -> table address 4 u (the table starts at LDS address 0)
-    auto lookup = [&](int t) -> uint32_t {
-      const uint32_t w = pw[t >> 2];
-      const uint32_t adr = (t & 3) == 3 ? (w >> 24) << 2 : (((w >> (8 * (t & 3))) & 0xffu) << 2);
-      return *(lds_cu32*)(uintptr_t)adr;
-    };
+#ifdef SF_EXPERIMENT_STAMP2
+    unsigned st2_t = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      if (j == 0 && dma_p) stageP(kx + AP, ipp);
-      if (j == 3 && dma_d) stageD(kx + AD, i3);
-      if (j < KS) {
-        if (do_x) {
-          if (j + PF < KS) xb[(j + PF) % NXB] = x_load(j + PF);
-          if (PARK > 0 && j + 3 >= KSR && j + 3 < KS) wt[j + 3 - KSR] = *(lds_cv4*)(uintptr_t)(aWP + (uint32_t)(j + 3 - KSR) * 1024u);
-          if (do_c) {
-            if (j == 1) cv_raw = *(lds_cv4*)(uintptr_t)base(aLN, uCs);
-            if (j == 5) *(lds_v4*)(uintptr_t)base(aL1, uC) = fp8x8_to_f16(cv_raw.x, cv_raw.y);
-            if (j == 8) *(lds_v4*)(uintptr_t)base(aL1x, uC + 1024u) = fp8x8_to_f16(cv_raw.z, cv_raw.w);
-          }
-          if (j == KS - LD - 3) pw = *(lds_cv4*)(uintptr_t)base(aLN, uEp);
-          g = OP::mfma(j < KSR ? wreg[j < KSR ? j : 0] : wt[j >= KSR ? j - KSR : 0], xb[j % NXB], g);
-        }
-        if (do_w) {
-          if (j == KS - 4) { bWb1 = base(aT1, uWs); bWb2 = base(aT2, uWs); wb_load(0, fb[0]); }
-          if (j == KS - 2) { bWa1 = base(aT1, uWd); bWa2 = base(aT2, uWd); fa[0] = wa_load(0, 0); }
-        }
-      } else {
-        const int i = (j - KS) >> 1, y = (j - KS) & 1, kk = i >> 2, x = i & 3;
-        if (do_w) {
-          if (y == 0 && i + 1 < 8) fa[(i + 1) & 1] = wa_load((i + 1) >> 2, (i + 1) & 3);
-          if (i == 1 && y == 1) wb_load(1, fb[1]);
-          acc[x][y] = OP::mfma(fa[i & 1], fb[kk][y], acc[x][y]);
-          if (x == DBX) {   // bias gradient: row sums of delta^T (two v_dot2_f32_f16 against (1, 1) per slot)
-            const h2 one2 = __builtin_bit_cast(h2, ones_h2);
-            const uint32_t f0 = y == 0 ? fa[i & 1].x : fa[i & 1].z, f1 = y == 0 ? fa[i & 1].y : fa[i & 1].w;
-            dbs = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f0), one2, dbs, false);
-            dbs = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f1), one2, dbs, false);
-          }
-        }
-      }
-      if (do_x) {
-        // E(kx): table pair of value t is looked up LD slots before the slot that forms the value
-        const int tl = j - (KS - LD);
-        if (tl >= 0 && tl < 16) tab[tl % NTAB] = lookup(tl);
-        const int t = j - KS;
-        if (t >= 0) {
-          const uint32_t e = tab[t % NTAB];
-          float sv = __builtin_fmaf((float)__builtin_bit_cast(h2, e)[1], g[t], 0.0f);      // cos * (W^T delta): v_fma_mix_f32
-          if (t & 1) {
-            const uint32_t e0 = tab[(t - 1) % NTAB];
-            // (saturation at +-448 by MODE.FP16_OVFL)
-            int w = (int)ep_d[t >> 2];
-            w = (t & 2) ? __builtin_amdgcn_cvt_pk_fp8_f32(sv_even, sv, w, true) : __builtin_amdgcn_cvt_pk_fp8_f32(sv_even, sv, w, false);   // (low half first: what stays in the high half is overwritten next)
-            ep_d[t >> 2] = (uint32_t)w;
-            const uint32_t sn = __builtin_amdgcn_perm(e, e0, 0x05040100u);      // (sin t-1, sin t)
-            if ((t & 3) == 1) ep_sn = sn;
-            else {
-              if (t == 3) bS = base(aL1, uEs);
-              if (t == 11) bSx = base(aL1x, uEs + 1024u);
-              *(lds_v2*)(uintptr_t)(((t >> 3) ? bSx : bS) + (uint32_t)(t & 4) * 2u) = u32x2{ep_sn, sn};
-            }
-          } else {
-            asm volatile("" : "+v"(sv));   // formed in its own slot
-            sv_even = sv;
-          }
-          if (t == 15) {
-#ifndef SF_EXPERIMENT_NO_STORE
-            a.Dout[((pb_begin + (long)(kx < nblk ? kx : nblk - 1) * pb_step) * NT + wave) * 64 + lane] = ep_d;
+    for (int j = 0; j < KS; ++j) {
+      if (j == 2 && dma == 1) stageD(dsrc, dslot);
+      if (j == 2 && dma == 2) stageP(dsrc, dslot);
+      if (j + PF < KS) xb[(j + PF) % NXB] = x_load(j + PF);
+      if (PARK > 0 && j + 3 >= KSR && j + 3 < KS) wt[j + 3 - KSR] = *(lds_cv4*)(uintptr_t)(aWP + (uint32_t)(j + 3 - KSR) * 1024u);
+      if (cvt) {
+        if (j == 1) cv_raw = *(lds_cv4*)(uintptr_t)base(aLN, uCs);
+#ifdef SF_EXP_NOCONVW
+        if (j == 5) { u32x4 v = fp8x8_to_f16(cv_raw.x, cv_raw.y); asm volatile("" ::"v"(v)); }
+        if (j == 8) { u32x4 v = fp8x8_to_f16(cv_raw.z, cv_raw.w); asm volatile("" ::"v"(v)); }
 #else
-            asm volatile("" ::"v"(ep_d));
+        if (j == 5) *(lds_v4*)(uintptr_t)base(aL1, uC) = fp8x8_to_f16(cv_raw.x, cv_raw.y);
+        if (j == 8) *(lds_v4*)(uintptr_t)base(aL1x, uC + 1024u) = fp8x8_to_f16(cv_raw.z, cv_raw.w);
+#endif
+      }
+      if (j == KS - LD - 3) pw = *(lds_cv4*)(uintptr_t)base(aLN, uEp);
+#ifdef SF_EXP_DUMMYCVT     // timing-only: the four conversions per slot a byte-fed phase X would issue
+      { u32x4 dv = fp8x8_to_f16(xb[j % NXB].x, xb[j % NXB].y); asm volatile("" ::"v"(dv)); }
+#endif
+      g = OP::mfma(j < KSR ? wreg[j < KSR ? j : 0] : wt[j >= KSR ? j - KSR : 0], xb[j % NXB], j == 0 ? f32x16{} : g);
+      if (pre >= 2 && j == KS - 4) { wo.b1 = base(aT1, w_uni_s(wsbuf)); wo.b2 = base(aT2, w_uni_s(wsbuf)); wb_load(wo, 0, fb[0]); }
+      if (pre >= 1 && j == KS - 2) { wo.a1 = base(aT1, w_uni_d(wdbuf)); wo.a2 = base(aT2, w_uni_d(wdbuf)); fa[0] = wa_load(wo, 0, 0); }
+      const int tl = j - (KS - LD);     // first table pairs of the epilogue that follows
+      if (tl >= 0) tab[tl % NTAB] = lookup(tl);
+      slot_end();
+#ifdef SF_EXPERIMENT_STAMP2
+      { const unsigned tn = (unsigned)__builtin_amdgcn_s_memtime(); st2[j] += tn - st2_t; st2_t = tn; }
+#endif
+    }
+  };
+  // W(kw) + E(ke): sbuf = S16 buffer the sines of block ke go to; odst = where this wave's piece of the deltas of block ke
+  // goes (the dump for blocks outside the chunk).  late_b: the sine fragments are requested here (N waves: S16(kw) was completed by the S
+  // waves in the half before).
+  auto phaseW = [&](u32x4* odst, uint32_t sbuf, bool cvt, uint32_t cbuf, int dma, const u32x4* dsrc, uint32_t dslot, bool late_b, uint32_t wsbuf, WOps& wo) __attribute__((always_inline)) {
+    const uint32_t uEs = oS16 + sbuf * 16384u + (uint32_t)wave * 2048u;
+    const uint32_t uC = oX16 + cbuf * 16384u + (uint32_t)wave * 2048u;
+    const uint32_t uCs = oRD + cbuf * 8192u + (uint32_t)wave * 1024u;
+    u32x4 cv_raw = {0u, 0u, 0u, 0u}, ep_d = {0u, 0u, 0u, 0u};
+    uint32_t ep_s[3] = {0u, 0u, 0u}, bS = 0, bSx = 0;
+    float sv_even = 0.f;
+#ifdef SF_EXPERIMENT_STAMP2
+    unsigned st2_t = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+    if (late_b) { wo.b1 = base(aT1, w_uni_s(wsbuf)); wo.b2 = base(aT2, w_uni_s(wsbuf)); wb_load(wo, 0, fb[0]); }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = t >> 1, y = t & 1, kk = i >> 2, x = i & 3;
+      if (t == 2 && dma == 1) stageD(dsrc, dslot);
+      if (t == 2 && dma == 2) stageP(dsrc, dslot);
+      if (y == 0 && i + 1 < 8) fa[(i + 1) & 1] = wa_load(wo, (i + 1) >> 2, (i + 1) & 3);
+      if (i == 1 && y == 1) wb_load(wo, 1, fb[1]);
+      if (cvt) {
+        if (t == 4) cv_raw = *(lds_cv4*)(uintptr_t)base(aLN, uCs);
+#ifdef SF_EXP_NOCONVW
+        if (t == 8) { u32x4 v = fp8x8_to_f16(cv_raw.x, cv_raw.y); asm volatile("" ::"v"(v)); }
+        if (t == 12) { u32x4 v = fp8x8_to_f16(cv_raw.z, cv_raw.w); asm volatile("" ::"v"(v)); }
+#else
+        if (t == 8) *(lds_v4*)(uintptr_t)base(aL1, uC) = fp8x8_to_f16(cv_raw.x, cv_raw.y);
+        if (t == 12) *(lds_v4*)(uintptr_t)base(aL1x, uC + 1024u) = fp8x8_to_f16(cv_raw.z, cv_raw.w);
+#endif
+      }
+#ifdef SF_EXP_DUMMYCVT
+      if (y == 0) { u32x4 dv = fp8x8_to_f16(fa[i & 1].x, fa[i & 1].y); asm volatile("" ::"v"(dv)); }
+#endif
+      acc[x][y] = OP::mfma(fa[i & 1], fb[kk][y], acc[x][y]);
+#ifndef SF_EXP_NODOT
+      if (x == DBX)
+#else
+      if (false)
+#endif
+      {   // bias gradient: row sums of delta^T (two v_dot2_f32_f16 against (1, 1) per slot)
+        const h2 one2 = __builtin_bit_cast(h2, ones_h2);
+        const uint32_t f0 = y == 0 ? fa[i & 1].x : fa[i & 1].z, f1 = y == 0 ? fa[i & 1].y : fa[i & 1].w;
+        dbs = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f0), one2, dbs, false);
+        dbs = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f1), one2, dbs, false);
+      }
+      // E: the table pair of value t was looked up LD slots ago; the pair of value t + LD is looked up now
+      if (t + LD < 16) tab[(t + LD) % NTAB] = lookup(t + LD);
+      {
+        const uint32_t e = tab[t % NTAB];
+        float sv = __builtin_fmaf((float)__builtin_bit_cast(h2, e)[1], g[t], 0.0f);      // cos * (W^T delta): v_fma_mix_f32
+        if (t & 1) {
+          const uint32_t e0 = tab[(t - 1) % NTAB];
+          // (saturation at +-448 by MODE.FP16_OVFL)
+          int w = (int)ep_d[t >> 2];
+          w = (t & 2) ? __builtin_amdgcn_cvt_pk_fp8_f32(sv_even, sv, w, true) : __builtin_amdgcn_cvt_pk_fp8_f32(sv_even, sv, w, false);   // (low half first: what stays in the high half is overwritten next)
+          ep_d[t >> 2] = (uint32_t)w;
+          const uint32_t sn = __builtin_amdgcn_perm(e, e0, 0x05040100u);      // (sin t-1, sin t)
+          // the eight sines of a k-step leave in ONE 16-byte write (conflict-free: eight lanes cover 128 contiguous bytes;
+          // two 8-byte writes per k-step were 2-way bank conflicts, and LDS stores are what this kernel has least room for:
+          // without them the kernel ran 12 % faster, SF_EXP_NOSINW)
+          if ((t & 7) != 7) ep_s[(t & 7) >> 1] = sn;
+          else {
+            if (t == 7) bS = base(aL1, uEs);
+            if (t == 15) bSx = base(aL1x, uEs + 1024u);
+#ifdef SF_EXP_NOSINW       // timing-only: sines are not written
+            asm volatile("" ::"v"(ep_s[0]), "v"(ep_s[1]), "v"(ep_s[2]), "v"(sn), "v"(bS), "v"(bSx));
+#else
+            *(lds_v4*)(uintptr_t)((t >> 3) ? bSx : bS) = u32x4{ep_s[0], ep_s[1], ep_s[2], sn};
 #endif
           }
+        } else {
+          asm volatile("" : "+v"(sv));   // formed in its own slot
+          sv_even = sv;
+        }
+        if (t == 15) {
+#ifndef SF_EXPERIMENT_NO_STORE
+          odst[lane] = ep_d;
+#else
+          asm volatile("" ::"v"(ep_d));
+#endif
         }
       }
       slot_end();
+#ifdef SF_EXPERIMENT_STAMP2
+      { const unsigned tn = (unsigned)__builtin_amdgcn_s_memtime(); st2[16 + t] += tn - st2_t; st2_t = tn; }
+#endif
     }
   };
 
   if (nblk > 0) {
-    // Ring protocol (as k_bwd8, with the byte ring feeding only the conversion).  Step k requests P(k + AP) then D(k + AD);
-    // the barrier at the top of step k needs D(k + 1) (expanded in step k) and P(k) landed.  D(k + 1) is the second request
-    // of step k - 2; younger in this wave's in-order vmcnt queue: the store of step k - 2 and the three operations of step
-    // k - 1 (requests beyond the last block are issued all the same, see stageD).
-    // EVERY step is the full step - there is no peeled first or last block (peeled copies cost hipcc ~80 spills each):
-    //   step 0 runs W(-1) on zero-filled images (adds exact zeros to dW and db);
-    //   step nblk runs W(nblk - 1) beside X/E of a duplicate of the last block, whose deltas are stored a second time to
-    //   the same place (same bytes).
-    for (int k = 0; k < AP; ++k) stageP(k, (uint32_t)k);
-    for (int k = 0; k < AD; ++k) stageD(k, (uint32_t)k);
-    {   // images of "block -1": X16 buffer 2, S16 buffer 1
+    // Ring protocol.  Step k (two halves, a barrier in front of each) requests D(k + 3) in its first half and P(k + AP) in
+    // its second; requests beyond the last block read zeros (deltas: the block then adds exact zeros to dW and db, and its
+    // outgoing deltas go to the dump) or the last block again (phase bytes: only their finiteness matters).  Every step is
+    // the full step: steps 0 and 1 run their W phases on zero-filled images, the last two on zero deltas.
+    // vmcnt: a wave's vector-memory operations per step, in issue order - N: D | P, store;  S: D, store | P.
+    //   N waves read P(k) at the end of the FIRST half of step k (requested in the second half of step k - 2): younger are
+    //   store(k-2), D, P, store of step k - 1 => vmcnt(4) at the first barrier; the older D(k + 1), expanded in the
+    //   second half, has landed with it.
+    //   S waves read D(k + 1) and P(k) in the SECOND half of step k: younger than P(k) are D, store, P of step k - 1 and D,
+    //   store of step k => vmcnt(5) at the second barrier.
+    for (int k = 0; k < AP; ++k) stageP(pP0 + (k < nblk ? k : nblk - 1) * blk_stride, (uint32_t)k);
+    for (int k = 0; k < AD; ++k) stageD(k < nblk ? pD0 + k * blk_stride : a.zeros, (uint32_t)k);
+    {   // zero images for the W phases of steps 0 and 1: X16 buffers 1 and 2 (C(0) fills buffer 0), both S16 buffers
       const u32x4 z = {0u, 0u, 0u, 0u};
       const uint32_t t16 = (uint32_t)(wave * 64 + lane) * 16u;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        *(lds_v4*)(uintptr_t)(oX16 + 2u * 16384u + (uint32_t)i * 8192u + t16) = z;
-        *(lds_v4*)(uintptr_t)(oS16 + 16384u + (uint32_t)i * 8192u + t16) = z;
+      for (int i = 0; i < 4; ++i) {
+        *(lds_v4*)(uintptr_t)(oX16 + 16384u + (uint32_t)i * 8192u + t16) = z;
+        *(lds_v4*)(uintptr_t)(oS16 + (uint32_t)i * 8192u + t16) = z;
       }
     }
     bar_all();
@@ -266,15 +350,68 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
       *(lds_v4*)(uintptr_t)(aL1 + oX16 + (uint32_t)wave * 2048u) = fp8x8_to_f16(raw.x, raw.y);
       *(lds_v4*)(uintptr_t)(aL1x + oX16 + (uint32_t)wave * 2048u + 1024u) = fp8x8_to_f16(raw.z, raw.w);
     }
+    WOps wo = {0u, 0u, 0u, 0u};
+    if (ROLE == 1) {   // the S waves' first W phase, W(-2): zero images
+      wo.b1 = base(aT1, w_uni_s(0u)); wo.b2 = base(aT2, w_uni_s(0u)); wb_load(wo, 0, fb[0]);
+      wo.a1 = base(aT1, w_uni_d(1u)); wo.a2 = base(aT2, w_uni_d(1u)); fa[0] = wa_load(wo, 0, 0);
+    }
     uint32_t i3 = 0, ip = 0;
-    for (int k = 0; k <= nblk; ++k) {
-      if (k >= 2) bar_dma<4>(); else bar_all();
-      step(k, i3, ip);
-      i3 = i3 == 2u ? 0u : i3 + 1u;
+    const u32x4* pD = pD0 + AD * blk_stride;                                       // D(k + AD)
+    const u32x4* pP = pP0 + (AP < nblk ? AP : nblk - 1) * blk_stride;              // P(min(k + AP, nblk - 1))
+    u32x4* pO = pO0;                                                               // deltas of block k
+    u32x4* const dump = a.dump + wave * 64;
+    // (the counted waits hold from step 0: what steps 0 and 1 read was requested above and has landed behind bar_all)
+    for (int k = 0; k <= nblk + 1; ++k) {
+      const uint32_t i3n = i3 == 2u ? 0u : i3 + 1u, i3p = i3 == 0u ? 2u : i3 - 1u, i2 = (uint32_t)(k & 1);
+      const uint32_t ipp = ip == 0u ? (uint32_t)(NBP - 1) : ip - 1u;      // ring slot of block k - 1 = of block k + AP
+      const u32x4* const dsrc = k + AD < nblk ? pD : a.zeros;
+      u32x4* const o_n = k < nblk ? pO : dump;                            // E(k)    (N waves)
+      u32x4* const o_s = (k >= 1 && k <= nblk) ? pO - blk_stride : dump;  // E(k-1)  (S waves)
+#ifdef SF_EXPERIMENT_STAMP
+      const unsigned long long t_b0 = __builtin_amdgcn_s_memtime();
+#endif
+      if (ROLE == 0) bar_dma<4>(); else bar_lds();
+#ifdef SF_EXPERIMENT_STAMP
+      const unsigned long long t_b1 = __builtin_amdgcn_s_memtime();
+#endif
+      if (ROLE == 0) phaseX(i3, false, 0u, 1, dsrc, i3, ip, 1, i3p, 0u, wo);                      // X(k); D(k+3); delta^T of W(k-1) requested
+      else phaseW(o_s, i2 ^ 1u, false, 0u, 1, dsrc, i3, false, 0u, wo);                           // W(k-2) + E(k-1); D(k+3)
+#ifdef SF_EXPERIMENT_STAMP
+      const unsigned long long t_b2 = __builtin_amdgcn_s_memtime();
+#endif
+      if (ROLE == 1) bar_dma<5>(); else bar_lds();
+#ifdef SF_EXPERIMENT_STAMP
+      const unsigned long long t_b3 = __builtin_amdgcn_s_memtime();
+#endif
+      if (ROLE == 0) phaseW(o_n, i2, true, i3n, 2, pP, ipp, true, i2 ^ 1u, wo);                   // W(k-1) + E(k); C(k+1); P(k+AP)
+      else phaseX(i3, true, i3n, 2, pP, ipp, ip, 2, i3p, i2 ^ 1u, wo);                            // X(k); C(k+1); P(k+AP); W(k-1) requested
+#ifdef SF_EXPERIMENT_STAMP
+      { const unsigned long long t_b4 = __builtin_amdgcn_s_memtime(); st_bar += (t_b1 - t_b0) + (t_b3 - t_b2); st_x += t_b2 - t_b1; st_w += t_b4 - t_b3; st_n += 1; }
+#endif
+#ifdef SF_EXPERIMENT_STAMP2
+      st2_n += 1;
+#endif
+      i3 = i3n;
       ip = ip == (uint32_t)(NBP - 1) ? 0u : ip + 1u;
+      pD += blk_stride;
+      pO += blk_stride;
+      if (k + AP + 1 < nblk) pP += blk_stride;
     }
     bar_all();     // no LDS-DMA of this workgroup is in flight when its LDS is handed on
   }
+#ifdef SF_EXPERIMENT_STAMP2
+  if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x == 3 && st2_n) {
+    float* o = a.dbg + (wave == 0 ? 0 : 32);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o[i] = (float)st2[i] / (float)st2_n;
+  }
+#endif
+#ifdef SF_EXPERIMENT_STAMP
+  if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 200) && st_n) {
+    float* o = a.dbg + 32 + ((blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 4;
+    o[0] = (float)st_bar / (float)st_n; o[1] = (float)st_x / (float)st_n; o[2] = (float)st_w / (float)st_n; o[3] = (float)st_n;
+  }
+#endif
   float* slab = a.slab + (size_t)blockIdx.x * (256 * 256 + 256);
   const int cl = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -299,15 +436,18 @@ __global__ __launch_bounds__(512) void k_bwd8h(Bwd8Args a) {
   __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef SF_BWD8H_ONEBODY
-  bwd8h_body<PARK, NBP, 0>(a, wave, lane);
-  return;
+#ifdef SF_BWD8H_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(SF_BWD8H_PRIO);
 #endif
-  switch (wave & 3) {
-    case 0: bwd8h_body<PARK, NBP, 0>(a, wave, lane); break;
-    case 1: bwd8h_body<PARK, NBP, 1>(a, wave, lane); break;
-    case 2: bwd8h_body<PARK, NBP, 2>(a, wave, lane); break;
-    default: bwd8h_body<PARK, NBP, 3>(a, wave, lane); break;
+  switch (wave) {   // (row group = role, column index = bias-gradient tile: every wave runs its own copy of the loop)
+    case 0: bwd8h_body<PARK, NBP, 0, 0>(a, wave, lane); break;
+    case 1: bwd8h_body<PARK, NBP, 1, 0>(a, wave, lane); break;
+    case 2: bwd8h_body<PARK, NBP, 2, 0>(a, wave, lane); break;
+    case 3: bwd8h_body<PARK, NBP, 3, 0>(a, wave, lane); break;
+    case 4: bwd8h_body<PARK, NBP, 0, 1>(a, wave, lane); break;
+    case 5: bwd8h_body<PARK, NBP, 1, 1>(a, wave, lane); break;
+    case 6: bwd8h_body<PARK, NBP, 2, 1>(a, wave, lane); break;
+    default: bwd8h_body<PARK, NBP, 3, 1>(a, wave, lane); break;
   }
 }
 
