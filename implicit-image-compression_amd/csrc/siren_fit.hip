@@ -335,15 +335,12 @@ int launch_bwd12(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) 
 #ifndef SF_BWD8H_PARK
 #define SF_BWD8H_PARK 3
 #endif
-#ifndef SF_BWD8H_NBP
-#define SF_BWD8H_NBP 3
-#endif
 int launch_bwd8h(sf_engine* h, const Bwd8Args& a, int n_wg) {
-  constexpr size_t lds = bwd8h_lds_bytes<SF_BWD8H_PARK, SF_BWD8H_NBP>();
+  constexpr size_t lds = bwd8h_lds_bytes<SF_BWD8H_PARK>();
   static_assert(lds <= 160 * 1024, "k_bwd8h LDS budget");
-  int rc = set_lds(k_bwd8h<SF_BWD8H_PARK, SF_BWD8H_NBP>, lds);
+  int rc = set_lds(k_bwd8h<SF_BWD8H_PARK>, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_bwd8h<SF_BWD8H_PARK, SF_BWD8H_NBP>), dim3(n_wg), dim3(512), lds, h->stream, a);
+  hipLaunchKernelGGL((k_bwd8h<SF_BWD8H_PARK>), dim3(n_wg), dim3(512), lds, h->stream, a);
   HIPCHK(hipGetLastError());
   return SF_OK;
 }

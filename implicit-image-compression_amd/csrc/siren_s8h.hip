@@ -1,5 +1,5 @@
 // siren_s8h.hip — k_bwd8h: the backward of one 256 x 256 HIDDEN layer from 8-bit scratch (phase bytes + fp8 deltas,
-// sf_config.scratch_format = 8) as ONE hand-cut software pipeline, one "slot" per MFMA (round 3).
+// sf_config.scratch_format = 8) as a hand-cut software pipeline, one "slot" per MFMA (round 3).
 //
 // Arithmetic: that of k_bwd8<256, 256, 2, 4, false, false, OpF16, .., D8 = true> (siren_s8.hip), bit for bit - the
 // autograd backward of implicit_image/models/siren.py:56-68 for one hidden layer l:
@@ -13,61 +13,73 @@
 //     (f16 half * f32); the sin/cos table sits at LDS address 0, so a table address is one v_lshlrev_b32_sdwa of the
 //     phase byte; all sixteen phase bytes of a lane come from one ds_read_b128 and all sixteen fp8 results leave in one
 //     16-byte store.
-//   * nothing is converted twice.  k_bwd8 read the delta^T fragments of phase W as bytes (ds_read_b64_tr_b8) and expanded
-//     them in registers - the four column waves of a row group each converting the same fragments (32 conversions per wave
-//     and block).  Here the block is expanded ONCE into a 16-bit image (X16, three buffers) that phase X reads
-//     lane-linearly and phase W reads transposed (ds_read_b64_tr_b16): 8 conversions per wave and block.  The byte ring
-//     then only feeds the conversion: three slots hold the three blocks in flight.
+//   * NO LDS STORE THAT IS NOT FORCED.  Measured on this kernel (timing-only builds, profiles/r03_*): an LDS store of
+//     1 KiB costs ~30 cycles of the LDS pipe, a 1 KiB read 4.  The 16-bit image of the deltas that both products read
+//     in the first form of this kernel (one conversion pass per block: 16 KiB of ds_write_b128) cost 13 % of the kernel.
+//     Both products now read the fp8 BYTES the LDS-DMA left in the ring and convert in registers (v_cvt_scalef32_pk_f16_fp8,
+//     exact): phase X one ds_read_b128 per two k-steps + 4 conversions per slot, phase W one ds_read_b64_tr_b8 per
+//     delta^T fragment + 4 conversions (scripts/probes/trb8.hip has the lane map; rows come out permuted by nu8, undone
+//     when the slab is written).  96 more conversions per wave and block for 16 KiB fewer stored and 16 KiB fewer read.
+//     The only LDS stores left are the sines (the weight-gradient product contracts over pixels: one transposition
+//     through LDS is forced), 16 bytes per lane and k-step.
 //   * the bias-gradient row sums are taken by ONE of the four column waves that hold the same fragments; which one is a
-//     compile-time constant of the wave's loop (the loop is instantiated per column wave), not a select per chunk.
-//   * every LDS read is issued a fixed number of slots before its first use (operand fragments, phase bytes, table pairs),
-//     the epilogue of block k is cut into sixteen single values, one per slot of phase W(k-1), and nothing crosses a
-//     slot boundary (sched_barrier + compiler memory barrier, as in k_fwd_pipe).
+//     compile-time constant of the wave's loop (the loop is instantiated per wave), not a select per chunk.
+//   * every LDS read is issued a fixed number of slots before its first use, the epilogue of a block is cut into sixteen
+//     single values, one per slot of a phase W, and nothing crosses a slot boundary (sched_barrier + compiler memory
+//     barrier, as in k_fwd_pipe).
+//   * THE TWO WAVES OF A SIMD RUN OPPOSITE PHASES (see the step loop).
 //
-// LDS of one workgroup (8 waves, 153 KiB with PARK = 2, NBP = 4):
+// LDS of one workgroup (8 waves; PARK = 3: 129 KiB):
 //   T     1 KiB          sin/cos pairs of the 256 phase bytes (two 16-bit floats per entry), at address 0
-//   RD    3 x  8 KiB     fp8 delta pieces of the blocks in flight (block k+3 is requested in step k, expanded in step k+2)
-//   RP    NBP x 8 KiB    phase-byte pieces (block k+NBP-1 is requested in step k, decoded in step k+NBP-1)
-//   X16   3 x 16 KiB     fp16 deltas: written in step k-1 (C), B operand in step k (X), read transposed in step k+1 (W)
-//   S16   2 x 16 KiB     fp16 sin(phase): written by the epilogue in step k, read transposed in step k+1 (W)
+//   RD    5 x  8 KiB     fp8 delta pieces: block k+3 is requested in step k; read by X(k) and, two steps later, by W(k)
+//   RP    4 x  8 KiB     phase-byte pieces: block k+3 is requested in step k, decoded at the end of X(k)
+//   S16   2 x 16 KiB     fp16 sin(phase): written by the epilogue E(k), read transposed by W(k)
 //   WP    8 x PARK KiB   the last PARK k-steps of every wave's stationary W_l^T rows (the rest lives in registers)
 // (included by siren_fit.hip after siren_s8.hip)
 
 namespace sf {
 
-#ifndef SF_BWD8H_PF
-#define SF_BWD8H_PF 1      // B pieces of phase X read ahead (register ring of PF + 1)
-#endif
 #ifndef SF_BWD8H_LD
 #define SF_BWD8H_LD 2      // slots between a table lookup and the value that uses it
 #endif
 
-template <int PARK, int NBP>
-constexpr size_t bwd8h_lds_bytes() { return (size_t)(1 + 3 * 8 + NBP * 8 + 3 * 16 + 2 * 16 + 8 * PARK) * 1024; }
+template <int PARK>
+constexpr size_t bwd8h_lds_bytes() { return (size_t)(1 + 5 * 8 + 4 * 8 + 2 * 16 + 8 * PARK) * 1024; }
 
 // DBX: the row tile (0..3) whose bias-gradient sums this instantiation takes (= the wave's column index wc)
 // ROLE: 0 = waves 0-3 ("N": X | W + E), 1 = waves 4-7 ("S", their SIMD partners: W + E | X)
-template <int PARK, int NBP, int DBX, int ROLE>
+template <int PARK, int DBX, int ROLE>
 __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, const int lane) {
   typedef OpF16 OP;
-  constexpr int KS = 16, NT = 8, NBD = 3, WJ = 4, WI = 2;
-  constexpr int AD = NBD, AP = NBP - 1;          // blocks requested ahead (deltas / phases)
-  constexpr int PF = SF_BWD8H_PF, NXB = PF + 1, LD = SF_BWD8H_LD, NTAB = LD + 2;   // (table ring: the pair of value t-1 is still read in slot t)
+  constexpr int KS = 16, NT = 8, NBD = 5, NBP = 4, WJ = 4, WI = 2;
+  constexpr int AD = 3, AP = 3;                  // blocks requested ahead (deltas / phases)
+  constexpr int LD = SF_BWD8H_LD, NTAB = LD + 2;   // (table ring: the pair of value t-1 is still read in slot t)
   constexpr int KSR = KS - PARK;
-  constexpr uint32_t oRD = 1024, oRP = oRD + NBD * 8192, oX16 = oRP + NBP * 8192, oS16 = oX16 + 3 * 16384, oWP = oS16 + 2 * 16384;
-  static_assert(PF >= 1 && PF <= 3 && LD >= 1 && LD <= 4 && PARK >= 0 && PARK <= 4 && NBP >= 3, "slot plan");
+  constexpr uint32_t oRD = 1024, oRP = oRD + NBD * 8192, oS16 = oRP + NBP * 8192, oWP = oS16 + 2 * 16384;
+  static_assert(LD >= 1 && LD <= 4 && PARK >= 0 && PARK <= 4, "slot plan");
   typedef __attribute__((address_space(3))) const u32x4 lds_cv4;
   typedef __attribute__((address_space(3))) u32x4 lds_v4;
   typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-  typedef __attribute__((address_space(3))) u32x2 lds_v2;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  typedef __attribute__((ext_vector_type(2))) int i32x2;
 
   const int wr = wave >> 2, wc = wave & 3;
   // lane patterns of the LDS accesses (everything else is a wave-uniform offset or a 16-bit immediate)
   const uint32_t aLN = (uint32_t)lane * 16u;                                   // lane-linear piece element
-  const uint32_t aL1 = (uint32_t)sw_lane(lane, 0) * 16u, aL1x = aL1 ^ 128u;     // swizzled piece element, even / odd k-step
-  const uint32_t aT1 = (uint32_t)tr_lane_base(lane), aT2 = aT1 ^ 64u;           // transposed-read lane bases
+  // byte pieces of the delta ring: slot i of a piece holds the element of lane i ^ 8 (i >> 5) - the upper lane half is
+  // shifted by eight pixels, i.e. by 32 banks, so that the even and odd row suppliers of a ds_read_b64_tr_b8 group do not
+  // meet on the same banks (as k_bwd8); the lane-linear 16-byte reads of phase X stay conflict-free under it
+  const uint32_t aL8 = (uint32_t)(lane ^ ((lane >> 5) << 3)) * 16u;
+  const uint32_t aL1 = (uint32_t)sw_lane(lane, 0) * 16u, aL1x = aL1 ^ 128u;     // swizzled 16-bit piece element, even / odd k-step
+  const uint32_t aT1 = (uint32_t)tr_lane_base(lane), aT2 = aT1 ^ 64u;           // transposed 16-bit reads (sines)
+  // transposed byte reads: ds_read_b64_tr_b8 works on groups of 16 lanes; lane t of a group supplies the address of an
+  // 8-byte row, result lane i < 8 receives byte i of the rows of lanes 0, 2, .., 14 and lane 8 + i byte i of the rows of
+  // lanes 1, 3, .., 15.  With lane t pointing at bytes 8q .. 8q+7 of piece lane (h' = t & 1, pixel 8 hq + (t >> 1)) -
+  // q = group & 1, hq = group >> 1 - the wave receives an A fragment of the 16-pixel k-step whose row r = lane & 31 is
+  // neuron nu8(r) of the tile and whose elements are the pixels 8 hq + 0..7 in order.
+  const uint32_t aT8 = 16u * (32u * (uint32_t)(lane & 1) + ((8u * (uint32_t)(lane >> 5) + (uint32_t)((lane & 15) >> 1)) ^ (8u * (uint32_t)(lane & 1)))) +
+                       8u * (uint32_t)((lane >> 4) & 1);
   uint32_t aWP = aLN + oWP + (uint32_t)(wave * PARK) * 1024u;                   // parked W_l^T k-steps of this wave
   asm volatile("" : "+v"(aWP));
 
@@ -106,7 +118,7 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   const u32x4* const pD0 = a.D + (pb_begin * NT + wave) * 64;
   const u32x4* const pP0 = a.P + (pb_begin * NT + wave) * 64;
   u32x4* const pO0 = a.Dout + (pb_begin * NT + wave) * 64;
-  auto stageD = [&](const u32x4* src, uint32_t slot) { glds16o(src, aLN, oRD + slot * 8192u + (uint32_t)wave * 1024u); };
+  auto stageD = [&](const u32x4* src, uint32_t slot) { glds16o(src, aL8, oRD + slot * 8192u + (uint32_t)wave * 1024u); };
   auto stageP = [&](const u32x4* src, uint32_t slot) { glds16o(src, aLN, oRP + slot * 8192u + (uint32_t)wave * 1024u); };
   auto slot_end = [&]() {
     asm volatile("" ::: "memory");
@@ -129,25 +141,27 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   unsigned st2_n = 0;
 #endif
   // ---- the two phases of a block, 16 slots each -----------------------------------------------------------------------
-  //   phase X(k)            16 MFMAs of the data-gradient product (one dependent chain), B pieces from X16(k)
+  //   phase X(k)            16 MFMAs of the data-gradient product (one dependent chain); B operand = the bytes of D(k),
+  //                         converted in registers one slot ahead
   //   phase W(kw) + E(ke)   16 MFMAs of the weight-gradient product of block kw beside the sixteen epilogue values of block
   //                         ke (cos * g -> fp8, sines -> S16(ke)); ke is the block whose phase X this wave ran last
   // THE TWO WAVES OF A SIMD RUN OPPOSITE PHASES (a stagger of half a block).  Waves 0-3 ("N") run X(k) | W(k-1)+E(k) in the
   // two halves of step k; their SIMD partners, waves 4-7 ("S"), run W(k-2)+E(k-1) | X(k).  Run in step, both waves of a
-  // SIMD were in the LDS-bound chain of phase X (all eight waves stream the same 16 KiB of deltas) and then both in the
-  // VALU-heavy phase W: the younger wave took 1 550-1 900 cycles for a phase X whose MFMAs need 1 024 per SIMD while the
-  // older one waited 800-1 000 cycles at the barrier.  Staggered, a phase X always runs beside a phase W: LDS, VALU and the
-  // matrix pipe see the same mix in every half.  Price: a second workgroup barrier per block (each half is closed by one),
-  // and E(k) of the S waves crosses a barrier (g, the phase bytes and the first table pairs stay in registers).
+  // SIMD were in the LDS-bound chain of phase X (all eight waves stream the same deltas) and then both in the VALU-heavy
+  // phase W: the younger wave took 1 550-1 900 cycles for a phase X whose MFMAs need 1 024 per SIMD while the older one
+  // waited 800-1 000 cycles at the barrier.  Staggered, a phase X always runs beside a phase W.  Price: a second workgroup
+  // barrier per block (each half is closed by one), and E(k) of the S waves crosses a barrier (g, the phase bytes and the
+  // first table pairs stay in registers).
   //   who needs what, with h = 2k (first half of step k) and h = 2k + 1 (second half):
-  //     X16(k+1)  written at h = 2k+1 by every wave (C(k+1), from the byte ring) - read by X(k+1) at h = 2k+2 (N), 2k+3 (S)
-  //               and by W(k+1) at h = 2k+5 (N), 2k+6 (S); its buffer is rewritten at h = 2k+7: three buffers
+  //     D(k)      read by X(k) at h = 2k (N), 2k+1 (S) and by W(k) at h = 2k+3 (N), 2k+4 (S); its ring slot is requested
+  //               again at h = 2k+5 (D(k+5), second half of step k+2): five slots
+  //     P(k)      read at the end of X(k): h = 2k (N), 2k+1 (S); its slot is requested again at h = 2k+2: four slots
   //     S16(k)    written at h = 2k+1 (N waves' tiles) and 2k+2 (S waves' tiles) - read at h = 2k+3 (N), 2k+4 (S); rewritten
   //               at h = 2k+5: two buffers
-  //     D(k+3)    requested at h = 2k into the ring slot C(k) emptied at h = 2k-1;  P(k+AP) requested at h = 2k+1 into the
-  //               slot whose bytes were last read at h = 2k-1 (S waves' E(k-1) reads them at the end of X(k-1))
-  u32x4 fa[2];
+  u32x2 fa8[2];                      // delta^T fragments as bytes (ring of two)
+  u32x4 fa;                          // the converted fragment of the current chunk
   u32x4 fb[2][WI];
+  u32x4 raw[2];                      // byte pieces of phase X (two k-steps each), ring of two
   f32x16 g = f32x16{};
   u32x4 pw = {0u, 0u, 0u, 0u};
   uint32_t tab[NTAB];
@@ -170,60 +184,55 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
 #endif
     return *(lds_cu32*)(uintptr_t)adr;
   };
-  struct WOps { uint32_t a1, a2, b1, b2; };      // base registers of the operand fragments of a phase W
-  auto wa_load = [&](const WOps& o, int kk, int x) -> u32x4 { return tr_pair(o.a1, o.a2, x * 2048 + kk * 256); };
+  struct WOps { uint32_t a, b1, b2; };      // base registers of the operand fragments of a phase W
+  auto wa_load = [&](const WOps& o, int kk, int x) -> u32x2 {
+    const i32x2 r = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(uintptr_t)(o.a + (uint32_t)(x * 1024 + kk * 256)));
+    return u32x2{(uint32_t)r.x, (uint32_t)r.y};
+  };
   auto wb_load = [&](const WOps& o, int kk, u32x4* dst) {
 #pragma unroll
     for (int y = 0; y < WI; ++y) dst[y] = tr_pair(o.b1, o.b2, y * 2048 + kk * 256);
   };
-  // byte offsets of the operand images of W(b): delta^T tiles of this wave's row group in X16(b), sine tiles of its column
-  // group in S16(b)
-  auto w_uni_d = [&](uint32_t x16buf) -> uint32_t { return oX16 + x16buf * 16384u + (uint32_t)(wr * WJ) * 2048u; };
-  auto w_uni_s = [&](uint32_t s16buf) -> uint32_t { return oS16 + s16buf * 16384u + (uint32_t)(wc * WI) * 2048u; };
+  // byte offsets of the operand images of W(b): delta tiles of this wave's row group in ring slot dslot, sine tiles of its
+  // column group in S16 buffer sbuf
+  auto w_uni_d = [&](uint32_t dslot) -> uint32_t { return oRD + dslot * 8192u + (uint32_t)(wr * WJ) * 1024u; };
+  auto w_uni_s = [&](uint32_t sbuf) -> uint32_t { return oS16 + sbuf * 16384u + (uint32_t)(wc * WI) * 2048u; };
+  // the first two byte pieces of X(b) (requested at the end of the phase before: D(b) has landed by then, see the loop)
+  auto x_pre = [&](uint32_t dslot) {
+    const uint32_t bX = base(aL8, oRD + dslot * 8192u);
+    raw[0] = *(lds_cv4*)(uintptr_t)bX;
+    raw[1] = *(lds_cv4*)(uintptr_t)(bX + 1024u);
+  };
 
-  // X(k): xbuf = X16 buffer of block k.  cvt: C(k+1) rides along (byte slot / X16 buffer cbuf).  dma: 0 none, 1 = D(k+3)
-  // into ring slot dslot, 2 = P(k+AP) into ring slot dslot.  pslot: ring slot of the phase bytes of block k (read for the
-  // epilogue that follows).  pre: the operand fragments of the NEXT phase W of this wave are requested at the end
-  // (S waves: both images are complete; N waves: only the delta^T image is).
-  auto phaseX = [&](uint32_t xbuf, bool cvt, uint32_t cbuf, int dma, const u32x4* dsrc, uint32_t dslot, uint32_t pslot, int pre, uint32_t wdbuf, uint32_t wsbuf, WOps& wo) __attribute__((always_inline)) {
-    const uint32_t uX = oX16 + xbuf * 16384u;
-    const uint32_t uC = oX16 + cbuf * 16384u + (uint32_t)wave * 2048u;                 // C: destination (k-steps 2 wave, 2 wave + 1)
-    const uint32_t uCs = oRD + cbuf * 8192u + (uint32_t)wave * 1024u;                  // C: byte piece
+  // X(k): dslot = ring slot of D(k).  dma: 0 none, 1 = a delta request, 2 = a phase-byte request (source dsrc, ring slot
+  // rslot).  pslot: ring slot of the phase bytes of block k (read for the epilogue that follows).  pre: the operand
+  // fragments of the NEXT phase W of this wave are requested at the end (S waves: both images are complete; N waves: only
+  // the delta bytes are).
+  auto phaseX = [&](uint32_t dslot, int dma, const u32x4* dsrc, uint32_t rslot, uint32_t pslot, int pre, uint32_t wdslot, uint32_t wsbuf, WOps& wo) __attribute__((always_inline)) {
     const uint32_t uEp = oRP + pslot * 8192u + (uint32_t)wave * 1024u;
-    const uint32_t bX0 = base(aL1, uX), bX1 = base(aL1x, uX);
-    auto x_load = [&](int c) -> u32x4 { return *(lds_cv4*)(uintptr_t)(((c & 1) ? bX1 : bX0) + (uint32_t)c * 1024u); };
-    u32x4 xb[NXB];
+    const uint32_t bX = base(aL8, oRD + dslot * 8192u);
     u32x4 wt[PARK > 0 ? PARK : 1];
-    u32x4 cv_raw = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int c = 0; c < PF; ++c) xb[c] = x_load(c);
+    u32x4 bq[2];                                   // converted B operands: slot j uses bq[j & 1]
+    bq[0] = fp8x8_to_f16(raw[0].x, raw[0].y);
     slot_end();
 #ifdef SF_EXPERIMENT_STAMP2
     unsigned st2_t = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
-      if (j == 2 && dma == 1) stageD(dsrc, dslot);
-      if (j == 2 && dma == 2) stageP(dsrc, dslot);
-      if (j + PF < KS) xb[(j + PF) % NXB] = x_load(j + PF);
+      if (j == 2 && dma == 1) stageD(dsrc, rslot);
+      if (j == 2 && dma == 2) stageP(dsrc, rslot);
+      // byte piece of k-steps j + 3, j + 4 (tile (j + 3) / 2), into the ring place its predecessor leaves in this slot
+      if ((j & 1) == 1 && j + 3 < KS) raw[((j + 3) >> 1) & 1] = *(lds_cv4*)(uintptr_t)(bX + (uint32_t)((j + 3) >> 1) * 1024u);
       if (PARK > 0 && j + 3 >= KSR && j + 3 < KS) wt[j + 3 - KSR] = *(lds_cv4*)(uintptr_t)(aWP + (uint32_t)(j + 3 - KSR) * 1024u);
-      if (cvt) {
-        if (j == 1) cv_raw = *(lds_cv4*)(uintptr_t)base(aLN, uCs);
-#ifdef SF_EXP_NOCONVW
-        if (j == 5) { u32x4 v = fp8x8_to_f16(cv_raw.x, cv_raw.y); asm volatile("" ::"v"(v)); }
-        if (j == 8) { u32x4 v = fp8x8_to_f16(cv_raw.z, cv_raw.w); asm volatile("" ::"v"(v)); }
-#else
-        if (j == 5) *(lds_v4*)(uintptr_t)base(aL1, uC) = fp8x8_to_f16(cv_raw.x, cv_raw.y);
-        if (j == 8) *(lds_v4*)(uintptr_t)base(aL1x, uC + 1024u) = fp8x8_to_f16(cv_raw.z, cv_raw.w);
-#endif
-      }
       if (j == KS - LD - 3) pw = *(lds_cv4*)(uintptr_t)base(aLN, uEp);
-#ifdef SF_EXP_DUMMYCVT     // timing-only: the four conversions per slot a byte-fed phase X would issue
-      { u32x4 dv = fp8x8_to_f16(xb[j % NXB].x, xb[j % NXB].y); asm volatile("" ::"v"(dv)); }
-#endif
-      g = OP::mfma(j < KSR ? wreg[j < KSR ? j : 0] : wt[j >= KSR ? j - KSR : 0], xb[j % NXB], j == 0 ? f32x16{} : g);
+      g = OP::mfma(j < KSR ? wreg[j < KSR ? j : 0] : wt[j >= KSR ? j - KSR : 0], bq[j & 1], j == 0 ? f32x16{} : g);
+      if (j + 1 < KS) {   // the B operand of the next slot: four conversions in the shadow of this slot's MFMA
+        const u32x4 r = raw[((j + 1) >> 1) & 1];
+        bq[(j + 1) & 1] = ((j + 1) & 1) ? fp8x8_to_f16(r.z, r.w) : fp8x8_to_f16(r.x, r.y);
+      }
       if (pre >= 2 && j == KS - 4) { wo.b1 = base(aT1, w_uni_s(wsbuf)); wo.b2 = base(aT2, w_uni_s(wsbuf)); wb_load(wo, 0, fb[0]); }
-      if (pre >= 1 && j == KS - 2) { wo.a1 = base(aT1, w_uni_d(wdbuf)); wo.a2 = base(aT2, w_uni_d(wdbuf)); fa[0] = wa_load(wo, 0, 0); }
+      if (pre >= 1 && j == KS - 2) { wo.a = base(aT8, w_uni_d(wdslot)); fa8[0] = wa_load(wo, 0, 0); fa8[1] = wa_load(wo, 0, 1); }
       const int tl = j - (KS - LD);     // first table pairs of the epilogue that follows
       if (tl >= 0) tab[tl % NTAB] = lookup(tl);
       slot_end();
@@ -233,40 +242,27 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
     }
   };
   // W(kw) + E(ke): sbuf = S16 buffer the sines of block ke go to; odst = where this wave's piece of the deltas of block ke
-  // goes (the dump for blocks outside the chunk).  late_b: the sine fragments are requested here (N waves: S16(kw) was completed by the S
-  // waves in the half before).
-  auto phaseW = [&](u32x4* odst, uint32_t sbuf, bool cvt, uint32_t cbuf, int dma, const u32x4* dsrc, uint32_t dslot, bool late_b, uint32_t wsbuf, WOps& wo) __attribute__((always_inline)) {
+  // goes (the dump for blocks outside the chunk).  late_b: the sine fragments are requested here (N waves: S16(kw) was
+  // completed by the S waves in the half before).  xslot: ring slot of the block whose phase X this wave runs next (its
+  // first byte pieces are requested at the end).
+  auto phaseW = [&](u32x4* odst, uint32_t sbuf, int dma, const u32x4* dsrc, uint32_t rslot, bool late_b, uint32_t wsbuf, uint32_t xslot, WOps& wo) __attribute__((always_inline)) {
     const uint32_t uEs = oS16 + sbuf * 16384u + (uint32_t)wave * 2048u;
-    const uint32_t uC = oX16 + cbuf * 16384u + (uint32_t)wave * 2048u;
-    const uint32_t uCs = oRD + cbuf * 8192u + (uint32_t)wave * 1024u;
-    u32x4 cv_raw = {0u, 0u, 0u, 0u}, ep_d = {0u, 0u, 0u, 0u};
+    u32x4 ep_d = {0u, 0u, 0u, 0u};
     uint32_t ep_s[3] = {0u, 0u, 0u}, bS = 0, bSx = 0;
     float sv_even = 0.f;
 #ifdef SF_EXPERIMENT_STAMP2
     unsigned st2_t = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
     if (late_b) { wo.b1 = base(aT1, w_uni_s(wsbuf)); wo.b2 = base(aT2, w_uni_s(wsbuf)); wb_load(wo, 0, fb[0]); }
+    fa = fp8x8_to_f16(fa8[0].x, fa8[0].y);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int i = t >> 1, y = t & 1, kk = i >> 2, x = i & 3;
-      if (t == 2 && dma == 1) stageD(dsrc, dslot);
-      if (t == 2 && dma == 2) stageP(dsrc, dslot);
-      if (y == 0 && i + 1 < 8) fa[(i + 1) & 1] = wa_load(wo, (i + 1) >> 2, (i + 1) & 3);
+      if (t == 2 && dma == 1) stageD(dsrc, rslot);
+      if (t == 2 && dma == 2) stageP(dsrc, rslot);
+      if (y == 0 && i + 2 < 8) fa8[i & 1] = wa_load(wo, (i + 2) >> 2, (i + 2) & 3);   // (the bytes of chunk i + 2: three slots before their conversion)
       if (i == 1 && y == 1) wb_load(wo, 1, fb[1]);
-      if (cvt) {
-        if (t == 4) cv_raw = *(lds_cv4*)(uintptr_t)base(aLN, uCs);
-#ifdef SF_EXP_NOCONVW
-        if (t == 8) { u32x4 v = fp8x8_to_f16(cv_raw.x, cv_raw.y); asm volatile("" ::"v"(v)); }
-        if (t == 12) { u32x4 v = fp8x8_to_f16(cv_raw.z, cv_raw.w); asm volatile("" ::"v"(v)); }
-#else
-        if (t == 8) *(lds_v4*)(uintptr_t)base(aL1, uC) = fp8x8_to_f16(cv_raw.x, cv_raw.y);
-        if (t == 12) *(lds_v4*)(uintptr_t)base(aL1x, uC + 1024u) = fp8x8_to_f16(cv_raw.z, cv_raw.w);
-#endif
-      }
-#ifdef SF_EXP_DUMMYCVT
-      if (y == 0) { u32x4 dv = fp8x8_to_f16(fa[i & 1].x, fa[i & 1].y); asm volatile("" ::"v"(dv)); }
-#endif
-      acc[x][y] = OP::mfma(fa[i & 1], fb[kk][y], acc[x][y]);
+      acc[x][y] = OP::mfma(fa, fb[kk][y], acc[x][y]);
 #ifndef SF_EXP_NODOT
       if (x == DBX)
 #else
@@ -274,10 +270,16 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
 #endif
       {   // bias gradient: row sums of delta^T (two v_dot2_f32_f16 against (1, 1) per slot)
         const h2 one2 = __builtin_bit_cast(h2, ones_h2);
-        const uint32_t f0 = y == 0 ? fa[i & 1].x : fa[i & 1].z, f1 = y == 0 ? fa[i & 1].y : fa[i & 1].w;
+        const uint32_t f0 = y == 0 ? fa.x : fa.z, f1 = y == 0 ? fa.y : fa.w;
         dbs = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f0), one2, dbs, false);
         dbs = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, f1), one2, dbs, false);
       }
+      if (y == 1 && i + 1 < 8) {   // the fragment of the next chunk (bytes requested three slots ago), behind this chunk's last MFMA
+        u32x4 nf = fp8x8_to_f16(fa8[(i + 1) & 1].x, fa8[(i + 1) & 1].y);
+        asm volatile("" : "+v"(nf));
+        fa = nf;
+      }
+      if (t == 13) x_pre(xslot);
       // E: the table pair of value t was looked up LD slots ago; the pair of value t + LD is looked up now
       if (t + LD < 16) tab[(t + LD) % NTAB] = lookup(t + LD);
       {
@@ -290,9 +292,7 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
           w = (t & 2) ? __builtin_amdgcn_cvt_pk_fp8_f32(sv_even, sv, w, true) : __builtin_amdgcn_cvt_pk_fp8_f32(sv_even, sv, w, false);   // (low half first: what stays in the high half is overwritten next)
           ep_d[t >> 2] = (uint32_t)w;
           const uint32_t sn = __builtin_amdgcn_perm(e, e0, 0x05040100u);      // (sin t-1, sin t)
-          // the eight sines of a k-step leave in ONE 16-byte write (conflict-free: eight lanes cover 128 contiguous bytes;
-          // two 8-byte writes per k-step were 2-way bank conflicts, and LDS stores are what this kernel has least room for:
-          // without them the kernel ran 12 % faster, SF_EXP_NOSINW)
+          // the eight sines of a k-step leave in ONE 16-byte write (conflict-free: eight lanes cover 128 contiguous bytes)
           if ((t & 7) != 7) ep_s[(t & 7) >> 1] = sn;
           else {
             if (t == 7) bS = base(aL1, uEs);
@@ -323,76 +323,74 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   };
 
   if (nblk > 0) {
-    // Ring protocol.  Step k (two halves, a barrier in front of each) requests D(k + 3) in its first half and P(k + AP) in
+    // Ring protocol.  Step k (two halves, a barrier in front of each) requests P(k + 3) in its first half and D(k + 3) in
     // its second; requests beyond the last block read zeros (deltas: the block then adds exact zeros to dW and db, and its
     // outgoing deltas go to the dump) or the last block again (phase bytes: only their finiteness matters).  Every step is
     // the full step: steps 0 and 1 run their W phases on zero-filled images, the last two on zero deltas.
-    // vmcnt: a wave's vector-memory operations per step, in issue order - N: D | P, store;  S: D, store | P.
-    //   N waves read P(k) at the end of the FIRST half of step k (requested in the second half of step k - 2): younger are
-    //   store(k-2), D, P, store of step k - 1 => vmcnt(4) at the first barrier; the older D(k + 1), expanded in the
-    //   second half, has landed with it.
-    //   S waves read D(k + 1) and P(k) in the SECOND half of step k: younger than P(k) are D, store, P of step k - 1 and D,
-    //   store of step k => vmcnt(5) at the second barrier.
+    // vmcnt: a wave's vector-memory operations per step, in issue order - N: P | D, store;  S: P, store | D.
+    //   N waves request the first byte pieces of X(k + 1) at the end of the SECOND half of step k: D(k + 1), requested in
+    //   the second half of step k - 2, must have landed at the barrier in front of that half; younger are store(k-2), the
+    //   three operations of step k - 1 and P of step k => vmcnt(5).  P(k + 1), decoded at the end of X(k + 1), is older.
+    //   S waves request the first byte pieces of X(k) at the end of the FIRST half of step k: D(k), requested in the second
+    //   half of step k - 3; younger are P, store, D of steps k - 2 and k - 1 => vmcnt(6) at the first barrier.
     for (int k = 0; k < AP; ++k) stageP(pP0 + (k < nblk ? k : nblk - 1) * blk_stride, (uint32_t)k);
     for (int k = 0; k < AD; ++k) stageD(k < nblk ? pD0 + k * blk_stride : a.zeros, (uint32_t)k);
-    {   // zero images for the W phases of steps 0 and 1: X16 buffers 1 and 2 (C(0) fills buffer 0), both S16 buffers
+    {   // zero images for the W phases of steps 0 and 1: ring slots 3 and 4 (blocks -2 and -1), both S16 buffers
       const u32x4 z = {0u, 0u, 0u, 0u};
       const uint32_t t16 = (uint32_t)(wave * 64 + lane) * 16u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *(lds_v4*)(uintptr_t)(oX16 + 16384u + (uint32_t)i * 8192u + t16) = z;
-        *(lds_v4*)(uintptr_t)(oS16 + (uint32_t)i * 8192u + t16) = z;
-      }
+      for (int i = 0; i < 2; ++i) *(lds_v4*)(uintptr_t)(oRD + 3u * 8192u + (uint32_t)i * 8192u + t16) = z;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(lds_v4*)(uintptr_t)(oS16 + (uint32_t)i * 8192u + t16) = z;
     }
     bar_all();
-    {   // C(0)
-      const u32x4 raw = *(lds_cv4*)(uintptr_t)(aLN + oRD + (uint32_t)wave * 1024u);
-      *(lds_v4*)(uintptr_t)(aL1 + oX16 + (uint32_t)wave * 2048u) = fp8x8_to_f16(raw.x, raw.y);
-      *(lds_v4*)(uintptr_t)(aL1x + oX16 + (uint32_t)wave * 2048u + 1024u) = fp8x8_to_f16(raw.z, raw.w);
-    }
-    WOps wo = {0u, 0u, 0u, 0u};
-    if (ROLE == 1) {   // the S waves' first W phase, W(-2): zero images
+    WOps wo = {0u, 0u, 0u};
+    if (ROLE == 0) x_pre(0u);            // X(0)
+    else {                               // the S waves' first W phase, W(-2): zero images
       wo.b1 = base(aT1, w_uni_s(0u)); wo.b2 = base(aT2, w_uni_s(0u)); wb_load(wo, 0, fb[0]);
-      wo.a1 = base(aT1, w_uni_d(1u)); wo.a2 = base(aT2, w_uni_d(1u)); fa[0] = wa_load(wo, 0, 0);
+      wo.a = base(aT8, w_uni_d(3u)); fa8[0] = wa_load(wo, 0, 0); fa8[1] = wa_load(wo, 0, 1);
     }
-    uint32_t i3 = 0, ip = 0;
-    const u32x4* pD = pD0 + AD * blk_stride;                                       // D(k + AD)
-    const u32x4* pP = pP0 + (AP < nblk ? AP : nblk - 1) * blk_stride;              // P(min(k + AP, nblk - 1))
+    uint32_t i5 = 0, i4 = 0;                                                       // k mod 5, k mod 4
+    const u32x4* pD = pD0 + AD * blk_stride;                                       // D(k + 3)
+    const u32x4* pP = pP0 + (AP < nblk ? AP : nblk - 1) * blk_stride;              // P(min(k + 3, nblk - 1))
     u32x4* pO = pO0;                                                               // deltas of block k
     u32x4* const dump = a.dump + wave * 64;
-    // (the counted waits hold from step 0: what steps 0 and 1 read was requested above and has landed behind bar_all)
+    // (the counted waits hold from step 0: what steps 0 to 2 read was requested above and has landed behind bar_all)
     for (int k = 0; k <= nblk + 1; ++k) {
-      const uint32_t i3n = i3 == 2u ? 0u : i3 + 1u, i3p = i3 == 0u ? 2u : i3 - 1u, i2 = (uint32_t)(k & 1);
-      const uint32_t ipp = ip == 0u ? (uint32_t)(NBP - 1) : ip - 1u;      // ring slot of block k - 1 = of block k + AP
+      const uint32_t i2 = (uint32_t)(k & 1);
+      const uint32_t i5n = i5 == 4u ? 0u : i5 + 1u;                       // ring slot of D(k + 1)
+      const uint32_t i5p = i5 == 0u ? 4u : i5 - 1u;                       // ring slot of D(k - 1)
+      const uint32_t i5pp = i5p == 0u ? 4u : i5p - 1u;                    // ring slot of D(k - 2) = of D(k + 3)
+      const uint32_t i4p = (i4 + 3u) & 3u;                                // ring slot of P(k - 1) = of P(k + 3)
       const u32x4* const dsrc = k + AD < nblk ? pD : a.zeros;
       u32x4* const o_n = k < nblk ? pO : dump;                            // E(k)    (N waves)
       u32x4* const o_s = (k >= 1 && k <= nblk) ? pO - blk_stride : dump;  // E(k-1)  (S waves)
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b0 = __builtin_amdgcn_s_memtime();
 #endif
-      if (ROLE == 0) bar_dma<4>(); else bar_lds();
+      if (ROLE == 1) bar_dma<6>(); else bar_lds();
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b1 = __builtin_amdgcn_s_memtime();
 #endif
-      if (ROLE == 0) phaseX(i3, false, 0u, 1, dsrc, i3, ip, 1, i3p, 0u, wo);                      // X(k); D(k+3); delta^T of W(k-1) requested
-      else phaseW(o_s, i2 ^ 1u, false, 0u, 1, dsrc, i3, false, 0u, wo);                           // W(k-2) + E(k-1); D(k+3)
+      if (ROLE == 0) phaseX(i5, 2, pP, i4p, i4, 1, i5p, 0u, wo);                          // X(k); P(k+3); delta^T of W(k-1) requested
+      else phaseW(o_s, i2 ^ 1u, 2, pP, i4p, false, 0u, i5, wo);                          // W(k-2) + E(k-1); P(k+3); bytes of X(k) requested
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b2 = __builtin_amdgcn_s_memtime();
 #endif
-      if (ROLE == 1) bar_dma<5>(); else bar_lds();
+      if (ROLE == 0) bar_dma<5>(); else bar_lds();
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b3 = __builtin_amdgcn_s_memtime();
 #endif
-      if (ROLE == 0) phaseW(o_n, i2, true, i3n, 2, pP, ipp, true, i2 ^ 1u, wo);                   // W(k-1) + E(k); C(k+1); P(k+AP)
-      else phaseX(i3, true, i3n, 2, pP, ipp, ip, 2, i3p, i2 ^ 1u, wo);                            // X(k); C(k+1); P(k+AP); W(k-1) requested
+      if (ROLE == 0) phaseW(o_n, i2, 1, dsrc, i5pp, true, i2 ^ 1u, i5n, wo);             // W(k-1) + E(k); D(k+3); bytes of X(k+1) requested
+      else phaseX(i5, 1, dsrc, i5pp, i4, 2, i5p, i2 ^ 1u, wo);                           // X(k); D(k+3); W(k-1) requested
 #ifdef SF_EXPERIMENT_STAMP
       { const unsigned long long t_b4 = __builtin_amdgcn_s_memtime(); st_bar += (t_b1 - t_b0) + (t_b3 - t_b2); st_x += t_b2 - t_b1; st_w += t_b4 - t_b3; st_n += 1; }
 #endif
 #ifdef SF_EXPERIMENT_STAMP2
       st2_n += 1;
 #endif
-      i3 = i3n;
-      ip = ip == (uint32_t)(NBP - 1) ? 0u : ip + 1u;
+      i5 = i5n;
+      i4 = (i4 + 1u) & 3u;
       pD += blk_stride;
       pO += blk_stride;
       if (k + AP + 1 < nblk) pP += blk_stride;
@@ -406,7 +404,7 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
     for (int i = 0; i < 32; ++i) o[i] = (float)st2[i] / (float)st2_n;
   }
 #endif
-#ifdef SF_EXPERIMENT_STAMP
+#if defined(SF_EXPERIMENT_STAMP) && !defined(SF_EXPERIMENT_STAMP2)
   if (a.dbg && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 200) && st_n) {
     float* o = a.dbg + 32 + ((blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 4;
     o[0] = (float)st_bar / (float)st_n; o[1] = (float)st_x / (float)st_n; o[2] = (float)st_w / (float)st_n; o[3] = (float)st_n;
@@ -420,14 +418,14 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
     for (int y = 0; y < WI; ++y)
 #pragma unroll
       for (int t = 0; t < 16; ++t)
-        slab[(size_t)(32 * (wr * WJ + x) + rho(t, hh)) * 256 + 32 * (wc * WI + y) + cl] = acc[x][y][t];
+        slab[(size_t)(32 * (wr * WJ + x) + nu8(rho(t, hh))) * 256 + 32 * (wc * WI + y) + cl] = acc[x][y][t];
   {
     const float tsum = dbs + __shfl_xor(dbs, 32);
-    if (hh == 0) slab[256 * 256 + 32 * (wr * WJ + DBX) + cl] = tsum;
+    if (hh == 0) slab[256 * 256 + 32 * (wr * WJ + DBX) + nu8(cl)] = tsum;
   }
 }
 
-template <int PARK, int NBP>
+template <int PARK>
 __global__ __launch_bounds__(512) void k_bwd8h(Bwd8Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the kernel addresses LDS absolutely (the table at address 0 is what makes a table address one instruction)
@@ -436,18 +434,15 @@ __global__ __launch_bounds__(512) void k_bwd8h(Bwd8Args a) {
   __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef SF_BWD8H_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(SF_BWD8H_PRIO);
-#endif
   switch (wave) {   // (row group = role, column index = bias-gradient tile: every wave runs its own copy of the loop)
-    case 0: bwd8h_body<PARK, NBP, 0, 0>(a, wave, lane); break;
-    case 1: bwd8h_body<PARK, NBP, 1, 0>(a, wave, lane); break;
-    case 2: bwd8h_body<PARK, NBP, 2, 0>(a, wave, lane); break;
-    case 3: bwd8h_body<PARK, NBP, 3, 0>(a, wave, lane); break;
-    case 4: bwd8h_body<PARK, NBP, 0, 1>(a, wave, lane); break;
-    case 5: bwd8h_body<PARK, NBP, 1, 1>(a, wave, lane); break;
-    case 6: bwd8h_body<PARK, NBP, 2, 1>(a, wave, lane); break;
-    default: bwd8h_body<PARK, NBP, 3, 1>(a, wave, lane); break;
+    case 0: bwd8h_body<PARK, 0, 0>(a, wave, lane); break;
+    case 1: bwd8h_body<PARK, 1, 0>(a, wave, lane); break;
+    case 2: bwd8h_body<PARK, 2, 0>(a, wave, lane); break;
+    case 3: bwd8h_body<PARK, 3, 0>(a, wave, lane); break;
+    case 4: bwd8h_body<PARK, 0, 1>(a, wave, lane); break;
+    case 5: bwd8h_body<PARK, 1, 1>(a, wave, lane); break;
+    case 6: bwd8h_body<PARK, 2, 1>(a, wave, lane); break;
+    default: bwd8h_body<PARK, 3, 1>(a, wave, lane); break;
   }
 }
 
