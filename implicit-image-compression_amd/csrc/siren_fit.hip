@@ -333,7 +333,7 @@ int launch_bwd12(sf_engine* h, bool last, bool p0, const Bwd8Args& a, int n_wg) 
   return fail(SF_ERR_INVALID, "unsupported hidden width");
 }
 #ifndef SF_BWD8H_PARK
-#define SF_BWD8H_PARK 3
+#define SF_BWD8H_PARK 4
 #endif
 int launch_bwd8h(sf_engine* h, const Bwd8Args& a, int n_wg) {
   constexpr size_t lds = bwd8h_lds_bytes<SF_BWD8H_PARK>();

@@ -29,11 +29,11 @@
 //     barrier, as in k_fwd_pipe).
 //   * THE TWO WAVES OF A SIMD RUN OPPOSITE PHASES (see the step loop).
 //
-// LDS of one workgroup (8 waves; PARK = 3: 129 KiB):
+// LDS of one workgroup (8 waves; PARK = 3: 145 KiB):
 //   T     1 KiB          sin/cos pairs of the 256 phase bytes (two 16-bit floats per entry), at address 0
 //   RD    5 x  8 KiB     fp8 delta pieces: block k+3 is requested in step k; read by X(k) and, two steps later, by W(k)
 //   RP    4 x  8 KiB     phase-byte pieces: block k+3 is requested in step k, decoded at the end of X(k)
-//   S16   2 x 16 KiB     fp16 sin(phase): written by the epilogue E(k), read transposed by W(k)
+//   S16   3 x 16 KiB     fp16 sin(phase): written during X(k) (the sines need the phase bytes only), read transposed by W(k)
 //   WP    8 x PARK KiB   the last PARK k-steps of every wave's stationary W_l^T rows (the rest lives in registers)
 // (included by siren_fit.hip after siren_s8.hip)
 
@@ -44,7 +44,7 @@ namespace sf {
 #endif
 
 template <int PARK>
-constexpr size_t bwd8h_lds_bytes() { return (size_t)(1 + 5 * 8 + 4 * 8 + 2 * 16 + 8 * PARK) * 1024; }
+constexpr size_t bwd8h_lds_bytes() { return (size_t)(1 + 5 * 8 + 4 * 8 + 3 * 16 + 8 * PARK) * 1024; }
 
 // DBX: the row tile (0..3) whose bias-gradient sums this instantiation takes (= the wave's column index wc)
 // ROLE: 0 = waves 0-3 ("N": X | W + E), 1 = waves 4-7 ("S", their SIMD partners: W + E | X)
@@ -53,9 +53,9 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   typedef OpF16 OP;
   constexpr int KS = 16, NT = 8, NBD = 5, NBP = 4, WJ = 4, WI = 2;
   constexpr int AD = 3, AP = 3;                  // blocks requested ahead (deltas / phases)
-  constexpr int LD = SF_BWD8H_LD, NTAB = LD + 2;   // (table ring: the pair of value t-1 is still read in slot t)
+  constexpr int LD = SF_BWD8H_LD, NTAB = 2 * (LD + 1);   // table ring of phase X: LD + 1 pairs in flight
   constexpr int KSR = KS - PARK;
-  constexpr uint32_t oRD = 1024, oRP = oRD + NBD * 8192, oS16 = oRP + NBP * 8192, oWP = oS16 + 2 * 16384;
+  constexpr uint32_t oRD = 1024, oRP = oRD + NBD * 8192, oS16 = oRP + NBP * 8192, oWP = oS16 + 3 * 16384;
   static_assert(LD >= 1 && LD <= 4 && PARK >= 0 && PARK <= 4, "slot plan");
   typedef __attribute__((address_space(3))) const u32x4 lds_cv4;
   typedef __attribute__((address_space(3))) u32x4 lds_v4;
@@ -163,10 +163,8 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   u32x4 fb[2][WI];
   u32x4 raw[2];                      // byte pieces of phase X (two k-steps each), ring of two
   f32x16 g = f32x16{};
-  u32x4 pw = {0u, 0u, 0u, 0u};
-  uint32_t tab[NTAB];
-#pragma unroll
-  for (int i = 0; i < NTAB; ++i) tab[i] = 0u;
+  uint32_t cp[4] = {0u, 0u, 0u, 0u};  // cosines of values 0..7 of the block whose phase X ran last, as 16-bit pairs
+  u32x2 pwh = {0u, 0u};               // phase bytes 8..15 of that block (their table pairs are looked up by the epilogue)
   // Per-step base registers = lane pattern + wave-uniform offset, formed where they are first needed and made opaque
   // (empty asm): a ds_* instruction takes one address register + a 16-bit immediate, and hipcc folds every constant it
   // can see into a 32-bit literal of a separate v_add per access otherwise (the LDS offsets here exceed 16 bits).
@@ -176,8 +174,7 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
     return b;
   };
   // phase-byte u of value t -> table address 4 u (the table starts at LDS address 0)
-  auto lookup = [&](int t) -> uint32_t {
-    const uint32_t w = pw[t >> 2];
+  auto lookup = [&](uint32_t w, int t) -> uint32_t {   // w = the dword that holds phase byte t
     const uint32_t adr = (t & 3) == 3 ? (w >> 24) << 2 : (((w >> (8 * (t & 3))) & 0xffu) << 2);
 #ifdef SF_EXP_NOLOOKUP     // timing-only: no table read
     return adr | 0x3c000000u;
@@ -208,12 +205,20 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   // rslot).  pslot: ring slot of the phase bytes of block k (read for the epilogue that follows).  pre: the operand
   // fragments of the NEXT phase W of this wave are requested at the end (S waves: both images are complete; N waves: only
   // the delta bytes are).
-  auto phaseX = [&](uint32_t dslot, int dma, const u32x4* dsrc, uint32_t rslot, uint32_t pslot, int pre, uint32_t wdslot, uint32_t wsbuf, WOps& wo) __attribute__((always_inline)) {
+  auto phaseX = [&](uint32_t dslot, int dma, const u32x4* dsrc, uint32_t rslot, uint32_t pslot, uint32_t sbuf, uint32_t wdslot, uint32_t wsbuf, WOps& wo) __attribute__((always_inline)) {
     const uint32_t uEp = oRP + pslot * 8192u + (uint32_t)wave * 1024u;
+    const uint32_t uEs = oS16 + sbuf * 16384u + (uint32_t)wave * 2048u;
     const uint32_t bX = base(aL8, oRD + dslot * 8192u);
     u32x4 wt[PARK > 0 ? PARK : 1];
     u32x4 bq[2];                                   // converted B operands: slot j uses bq[j & 1]
+    u32x4 pw;                                      // the sixteen phase bytes of this lane
+    uint32_t tab[NTAB];                            // table pairs in flight
+    uint32_t sp[4];                                // sines of a k-step, as 16-bit pairs
+#ifdef SF_BWD8H_XPRIO
+    __builtin_amdgcn_s_setprio(SF_BWD8H_XPRIO);
+#endif
     bq[0] = fp8x8_to_f16(raw[0].x, raw[0].y);
+    pw = *(lds_cv4*)(uintptr_t)base(aLN, uEp);
     slot_end();
 #ifdef SF_EXPERIMENT_STAMP2
     unsigned st2_t = (unsigned)__builtin_amdgcn_s_memtime();
@@ -224,36 +229,68 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
       if (j == 2 && dma == 2) stageP(dsrc, rslot);
       // byte piece of k-steps j + 3, j + 4 (tile (j + 3) / 2), into the ring place its predecessor leaves in this slot
       if ((j & 1) == 1 && j + 3 < KS) raw[((j + 3) >> 1) & 1] = *(lds_cv4*)(uintptr_t)(bX + (uint32_t)((j + 3) >> 1) * 1024u);
-      if (PARK > 0 && j + 3 >= KSR && j + 3 < KS) wt[j + 3 - KSR] = *(lds_cv4*)(uintptr_t)(aWP + (uint32_t)(j + 3 - KSR) * 1024u);
-      if (j == KS - LD - 3) pw = *(lds_cv4*)(uintptr_t)base(aLN, uEp);
-      g = OP::mfma(j < KSR ? wreg[j < KSR ? j : 0] : wt[j >= KSR ? j - KSR : 0], bq[j & 1], j == 0 ? f32x16{} : g);
-      if (j + 1 < KS) {   // the B operand of the next slot: four conversions in the shadow of this slot's MFMA
+      if (PARK > 0 && j + 2 >= KSR && j + 2 < KS) wt[j + 2 - KSR] = *(lds_cv4*)(uintptr_t)(aWP + (uint32_t)(j + 2 - KSR) * 1024u);
+      if (j + 1 < KS) {   // the B operand of the NEXT slot: four conversions, ahead of this slot's MFMA (a conversion right in front
+                          // of the MFMA that reads it costs two wait states: s_nop 1 in every slot)
         const u32x4 r = raw[((j + 1) >> 1) & 1];
         bq[(j + 1) & 1] = ((j + 1) & 1) ? fp8x8_to_f16(r.z, r.w) : fp8x8_to_f16(r.x, r.y);
       }
-      if (pre >= 2 && j == KS - 4) { wo.b1 = base(aT1, w_uni_s(wsbuf)); wo.b2 = base(aT2, w_uni_s(wsbuf)); wb_load(wo, 0, fb[0]); }
-      if (pre >= 1 && j == KS - 2) { wo.a = base(aT8, w_uni_d(wdslot)); fa8[0] = wa_load(wo, 0, 0); fa8[1] = wa_load(wo, 0, 1); }
-      const int tl = j - (KS - LD);     // first table pairs of the epilogue that follows
-      if (tl >= 0) tab[tl % NTAB] = lookup(tl);
+      __builtin_amdgcn_sched_barrier(0);
+      g = OP::mfma(j < KSR ? wreg[j < KSR ? j : 0] : wt[j >= KSR ? j - KSR : 0], bq[j & 1], j == 0 ? f32x16{} : g);
+      // The phase bytes are all the sines and cosines need, so HALF of that work is done here (values 0..7: the first
+      // k-step of this wave's tile) and half in the epilogue (values 8..15): what bounds a phase is its count of vector
+      // and LDS instructions per MFMA slot - about six per slot are hidden beside the MFMAs of two waves, every further one
+      // costs ~5 cycles (timing-only builds, profiles/r03_*) - and this split levels the two phases.
+      // Values 2i, 2i + 1 are looked up in slot i + 1 (i = 0..3) and split LD slots later: the sine pair goes into the pair
+      // registers of the k-step (one 16-byte write), the cosine pair into cp[i] for the epilogue.
+      if (j >= 1 && j <= 4) { tab[(2 * (j - 1)) % NTAB] = lookup(pw[(j - 1) >> 1], 2 * (j - 1)); tab[(2 * (j - 1) + 1) % NTAB] = lookup(pw[(j - 1) >> 1], 2 * (j - 1) + 1); }
+      {
+        const int i = j - 1 - LD;          // pair split in this slot
+        if (i >= 0 && i < 4) {
+          const uint32_t e0 = tab[(2 * i) % NTAB], e1 = tab[(2 * i + 1) % NTAB];
+          uint32_t sn = __builtin_amdgcn_perm(e1, e0, 0x05040100u);      // (sin 2i, sin 2i+1)
+          uint32_t cs = __builtin_amdgcn_perm(e1, e0, 0x07060302u);      // (cos 2i, cos 2i+1)
+          asm volatile("" : "+v"(sn), "+v"(cs));
+          cp[i] = cs;
+          sp[i] = sn;
+#ifndef SF_EXP_NOSINW
+          if (i == 3) *(lds_v4*)(uintptr_t)base(aL1, uEs) = u32x4{sp[0], sp[1], sp[2], sp[3]};
+#endif
+        }
+      }
+      if (j == 5) pwh = u32x2{pw.z, pw.w};
+      // (S waves only: the N waves' next phase W reads sines the S waves are still writing in this half)
+#ifdef SF_EXP_NPRE   // timing-only (races with the S waves' sine writes)
+      if (j == KS - 4)
+#else
+      if (ROLE == 1 && j == KS - 4)
+#endif
+      { wo.b1 = base(aT1, w_uni_s(wsbuf)); wo.b2 = base(aT2, w_uni_s(wsbuf)); wb_load(wo, 0, fb[0]); }
+      if (j == KS - 2) { wo.a = base(aT8, w_uni_d(wdslot)); fa8[0] = wa_load(wo, 0, 0); fa8[1] = wa_load(wo, 0, 1); }
       slot_end();
 #ifdef SF_EXPERIMENT_STAMP2
       { const unsigned tn = (unsigned)__builtin_amdgcn_s_memtime(); st2[j] += tn - st2_t; st2_t = tn; }
 #endif
     }
   };
-  // W(kw) + E(ke): sbuf = S16 buffer the sines of block ke go to; odst = where this wave's piece of the deltas of block ke
-  // goes (the dump for blocks outside the chunk).  late_b: the sine fragments are requested here (N waves: S16(kw) was
-  // completed by the S waves in the half before).  xslot: ring slot of the block whose phase X this wave runs next (its
-  // first byte pieces are requested at the end).
-  auto phaseW = [&](u32x4* odst, uint32_t sbuf, int dma, const u32x4* dsrc, uint32_t rslot, bool late_b, uint32_t wsbuf, uint32_t xslot, WOps& wo) __attribute__((always_inline)) {
+  // W(kw) + E(ke): odst = where this wave's piece of the deltas of block ke goes (the dump for blocks outside the chunk).
+  // xslot: ring slot of the block whose phase X this wave runs next (its first byte pieces are requested at the end).
+  auto phaseW = [&](u32x4* odst, uint32_t sbuf, uint32_t wsbuf, int dma, const u32x4* dsrc, uint32_t rslot, uint32_t xslot, WOps& wo) __attribute__((always_inline)) {
     const uint32_t uEs = oS16 + sbuf * 16384u + (uint32_t)wave * 2048u;
-    u32x4 ep_d = {0u, 0u, 0u, 0u};
-    uint32_t ep_s[3] = {0u, 0u, 0u}, bS = 0, bSx = 0;
     float sv_even = 0.f;
+    u32x4 ep_d;                        // outgoing fp8 deltas (every byte is written before the store: no initial value)
+    asm volatile("" : "=v"(ep_d));
+    uint32_t tab[LD + 2];              // table pairs of values 8..15 in flight (the pair of value t-1 is still read in slot t)
+    uint32_t sp[3] = {0u, 0u, 0u};
 #ifdef SF_EXPERIMENT_STAMP2
     unsigned st2_t = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-    if (late_b) { wo.b1 = base(aT1, w_uni_s(wsbuf)); wo.b2 = base(aT2, w_uni_s(wsbuf)); wb_load(wo, 0, fb[0]); }
+#ifdef SF_BWD8H_WPRIO
+    __builtin_amdgcn_s_setprio(SF_BWD8H_WPRIO);
+#endif
+#ifndef SF_EXP_NPRE
+    if (ROLE == 0) { wo.b1 = base(aT1, w_uni_s(wsbuf)); wo.b2 = base(aT2, w_uni_s(wsbuf)); wb_load(wo, 0, fb[0]); }   // (N waves: S16(kw) was completed in the half before)
+#endif
     fa = fp8x8_to_f16(fa8[0].x, fa8[0].y);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -280,27 +317,22 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
         fa = nf;
       }
       if (t == 13) x_pre(xslot);
-      // E: the table pair of value t was looked up LD slots ago; the pair of value t + LD is looked up now
-      if (t + LD < 16) tab[(t + LD) % NTAB] = lookup(t + LD);
+      // E: cos * (W^T delta) -> fp8 (saturation at +-448 by MODE.FP16_OVFL): v_fma_mix_f32 + half a v_cvt_pk_fp8_f32 per
+      // value.  Values 0..7 take their cosines from cp[] (phase X); values 8..15 are looked up here, LD slots ahead, and
+      // their sines leave in the 16-byte write of the tile's second k-step.
+      if (t + LD >= 8 && t + LD < 16) tab[(t + LD) % (LD + 2)] = lookup((t + LD) < 12 ? pwh.x : pwh.y, t + LD);
       {
-        const uint32_t e = tab[t % NTAB];
-        float sv = __builtin_fmaf((float)__builtin_bit_cast(h2, e)[1], g[t], 0.0f);      // cos * (W^T delta): v_fma_mix_f32
+        const uint32_t e = t < 8 ? cp[t >> 1] : tab[t % (LD + 2)];
+        float sv = __builtin_fmaf((float)__builtin_bit_cast(h2, e)[t < 8 ? (t & 1) : 1], g[t], 0.0f);
         if (t & 1) {
-          const uint32_t e0 = tab[(t - 1) % NTAB];
-          // (saturation at +-448 by MODE.FP16_OVFL)
           int w = (int)ep_d[t >> 2];
           w = (t & 2) ? __builtin_amdgcn_cvt_pk_fp8_f32(sv_even, sv, w, true) : __builtin_amdgcn_cvt_pk_fp8_f32(sv_even, sv, w, false);   // (low half first: what stays in the high half is overwritten next)
           ep_d[t >> 2] = (uint32_t)w;
-          const uint32_t sn = __builtin_amdgcn_perm(e, e0, 0x05040100u);      // (sin t-1, sin t)
-          // the eight sines of a k-step leave in ONE 16-byte write (conflict-free: eight lanes cover 128 contiguous bytes)
-          if ((t & 7) != 7) ep_s[(t & 7) >> 1] = sn;
-          else {
-            if (t == 7) bS = base(aL1, uEs);
-            if (t == 15) bSx = base(aL1x, uEs + 1024u);
-#ifdef SF_EXP_NOSINW       // timing-only: sines are not written
-            asm volatile("" ::"v"(ep_s[0]), "v"(ep_s[1]), "v"(ep_s[2]), "v"(sn), "v"(bS), "v"(bSx));
-#else
-            *(lds_v4*)(uintptr_t)((t >> 3) ? bSx : bS) = u32x4{ep_s[0], ep_s[1], ep_s[2], sn};
+          if (t >= 9) {
+            const uint32_t sn = __builtin_amdgcn_perm(e, tab[(t - 1) % (LD + 2)], 0x05040100u);      // (sin t-1, sin t)
+            if (t < 15) sp[(t - 9) >> 1] = sn;
+#ifndef SF_EXP_NOSINW
+            else *(lds_v4*)(uintptr_t)base(aL1x, uEs + 1024u) = u32x4{sp[0], sp[1], sp[2], sn};
 #endif
           }
         } else {
@@ -335,29 +367,29 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
     //   half of step k - 3; younger are P, store, D of steps k - 2 and k - 1 => vmcnt(6) at the first barrier.
     for (int k = 0; k < AP; ++k) stageP(pP0 + (k < nblk ? k : nblk - 1) * blk_stride, (uint32_t)k);
     for (int k = 0; k < AD; ++k) stageD(k < nblk ? pD0 + k * blk_stride : a.zeros, (uint32_t)k);
-    {   // zero images for the W phases of steps 0 and 1: ring slots 3 and 4 (blocks -2 and -1), both S16 buffers
+    {   // zero images for the W phases of steps 0 and 1: ring slots 3 and 4 (blocks -2 and -1), the S16 buffers
       const u32x4 z = {0u, 0u, 0u, 0u};
       const uint32_t t16 = (uint32_t)(wave * 64 + lane) * 16u;
 #pragma unroll
       for (int i = 0; i < 2; ++i) *(lds_v4*)(uintptr_t)(oRD + 3u * 8192u + (uint32_t)i * 8192u + t16) = z;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *(lds_v4*)(uintptr_t)(oS16 + (uint32_t)i * 8192u + t16) = z;
+      for (int i = 0; i < 6; ++i) *(lds_v4*)(uintptr_t)(oS16 + (uint32_t)i * 8192u + t16) = z;
     }
     bar_all();
     WOps wo = {0u, 0u, 0u};
     if (ROLE == 0) x_pre(0u);            // X(0)
     else {                               // the S waves' first W phase, W(-2): zero images
-      wo.b1 = base(aT1, w_uni_s(0u)); wo.b2 = base(aT2, w_uni_s(0u)); wb_load(wo, 0, fb[0]);
+      wo.b1 = base(aT1, w_uni_s(1u)); wo.b2 = base(aT2, w_uni_s(1u)); wb_load(wo, 0, fb[0]);
       wo.a = base(aT8, w_uni_d(3u)); fa8[0] = wa_load(wo, 0, 0); fa8[1] = wa_load(wo, 0, 1);
     }
-    uint32_t i5 = 0, i4 = 0;                                                       // k mod 5, k mod 4
+    uint32_t i5 = 0, i4 = 0, i3 = 0;                                               // k mod 5, k mod 4, k mod 3
     const u32x4* pD = pD0 + AD * blk_stride;                                       // D(k + 3)
     const u32x4* pP = pP0 + (AP < nblk ? AP : nblk - 1) * blk_stride;              // P(min(k + 3, nblk - 1))
     u32x4* pO = pO0;                                                               // deltas of block k
     u32x4* const dump = a.dump + wave * 64;
     // (the counted waits hold from step 0: what steps 0 to 2 read was requested above and has landed behind bar_all)
     for (int k = 0; k <= nblk + 1; ++k) {
-      const uint32_t i2 = (uint32_t)(k & 1);
+      const uint32_t i3p = i3 == 0u ? 2u : i3 - 1u;                       // S16 buffer of block k - 1
       const uint32_t i5n = i5 == 4u ? 0u : i5 + 1u;                       // ring slot of D(k + 1)
       const uint32_t i5p = i5 == 0u ? 4u : i5 - 1u;                       // ring slot of D(k - 1)
       const uint32_t i5pp = i5p == 0u ? 4u : i5p - 1u;                    // ring slot of D(k - 2) = of D(k + 3)
@@ -372,8 +404,8 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b1 = __builtin_amdgcn_s_memtime();
 #endif
-      if (ROLE == 0) phaseX(i5, 2, pP, i4p, i4, 1, i5p, 0u, wo);                          // X(k); P(k+3); delta^T of W(k-1) requested
-      else phaseW(o_s, i2 ^ 1u, 2, pP, i4p, false, 0u, i5, wo);                          // W(k-2) + E(k-1); P(k+3); bytes of X(k) requested
+      if (ROLE == 0) phaseX(i5, 2, pP, i4p, i4, i3, i5p, i3p, wo);                        // X(k) + sines(k); P(k+3); operands of W(k-1) requested
+      else phaseW(o_s, i3p, 0u, 2, pP, i4p, i5, wo);                                           // W(k-2) + E(k-1); P(k+3); bytes of X(k) requested
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -381,8 +413,8 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b3 = __builtin_amdgcn_s_memtime();
 #endif
-      if (ROLE == 0) phaseW(o_n, i2, 1, dsrc, i5pp, true, i2 ^ 1u, i5n, wo);             // W(k-1) + E(k); D(k+3); bytes of X(k+1) requested
-      else phaseX(i5, 1, dsrc, i5pp, i4, 2, i5p, i2 ^ 1u, wo);                           // X(k); D(k+3); W(k-1) requested
+      if (ROLE == 0) phaseW(o_n, i3, i3p, 1, dsrc, i5pp, i5n, wo);                            // W(k-1) + E(k); D(k+3); bytes of X(k+1) requested
+      else phaseX(i5, 1, dsrc, i5pp, i4, i3, i5p, i3p, wo);                              // X(k) + sines(k); D(k+3); operands of W(k-1) requested
 #ifdef SF_EXPERIMENT_STAMP
       { const unsigned long long t_b4 = __builtin_amdgcn_s_memtime(); st_bar += (t_b1 - t_b0) + (t_b3 - t_b2); st_x += t_b2 - t_b1; st_w += t_b4 - t_b3; st_n += 1; }
 #endif
@@ -391,6 +423,7 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
 #endif
       i5 = i5n;
       i4 = (i4 + 1u) & 3u;
+      i3 = i3 == 2u ? 0u : i3 + 1u;
       pD += blk_stride;
       pO += blk_stride;
       if (k + AP + 1 < nblk) pP += blk_stride;
