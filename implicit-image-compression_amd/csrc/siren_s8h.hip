@@ -118,8 +118,8 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   const u32x4* const pD0 = a.D + (pb_begin * NT + wave) * 64;
   const u32x4* const pP0 = a.P + (pb_begin * NT + wave) * 64;
   u32x4* const pO0 = a.Dout + (pb_begin * NT + wave) * 64;
-  auto stageD = [&](const u32x4* src, uint32_t slot) { glds16o(src, aL8, oRD + slot * 8192u + (uint32_t)wave * 1024u); };
-  auto stageP = [&](const u32x4* src, uint32_t slot) { glds16o(src, aLN, oRP + slot * 8192u + (uint32_t)wave * 1024u); };
+  auto stageD = [&](const u32x4* src, uint32_t off) { glds16o(src, aL8, oRD + off + (uint32_t)wave * 1024u); };        // off = ring slot * 8 KiB
+  auto stageP = [&](const u32x4* src, uint32_t off) { glds16o(src, aLN, oRP + off + (uint32_t)wave * 1024u); };
   auto slot_end = [&]() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -173,9 +173,15 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
     asm volatile("" : "+v"(b));
     return b;
   };
+  const uint32_t two_s = __builtin_amdgcn_readfirstlane(2u);   // (the shift count of the SDWA form, in a scalar register)
   // phase-byte u of value t -> table address 4 u (the table starts at LDS address 0)
   auto lookup = [&](uint32_t w, int t) -> uint32_t {   // w = the dword that holds phase byte t
-    const uint32_t adr = (t & 3) == 3 ? (w >> 24) << 2 : (((w >> (8 * (t & 3))) & 0xffu) << 2);
+    uint32_t adr;
+    if ((t & 3) == 0) {   // byte 0: hipcc emits v_lshlrev + v_and for (w & 0xff) << 2; the SDWA form is one instruction
+      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(adr) : "s"(two_s), "v"(w));
+    } else {
+      adr = (t & 3) == 3 ? (w >> 24) << 2 : (((w >> (8 * (t & 3))) & 0xffu) << 2);
+    }
 #ifdef SF_EXP_NOLOOKUP     // timing-only: no table read
     return adr | 0x3c000000u;
 #endif
@@ -192,11 +198,11 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   };
   // byte offsets of the operand images of W(b): delta tiles of this wave's row group in ring slot dslot, sine tiles of its
   // column group in S16 buffer sbuf
-  auto w_uni_d = [&](uint32_t dslot) -> uint32_t { return oRD + dslot * 8192u + (uint32_t)(wr * WJ) * 1024u; };
-  auto w_uni_s = [&](uint32_t sbuf) -> uint32_t { return oS16 + sbuf * 16384u + (uint32_t)(wc * WI) * 2048u; };
+  auto w_uni_d = [&](uint32_t doff) -> uint32_t { return oRD + doff + (uint32_t)(wr * WJ) * 1024u; };
+  auto w_uni_s = [&](uint32_t soff) -> uint32_t { return oS16 + soff + (uint32_t)(wc * WI) * 2048u; };
   // the first two byte pieces of X(b) (requested at the end of the phase before: D(b) has landed by then, see the loop)
-  auto x_pre = [&](uint32_t dslot) {
-    const uint32_t bX = base(aL8, oRD + dslot * 8192u);
+  auto x_pre = [&](uint32_t doff) {
+    const uint32_t bX = base(aL8, oRD + doff);
     raw[0] = *(lds_cv4*)(uintptr_t)bX;
     raw[1] = *(lds_cv4*)(uintptr_t)(bX + 1024u);
   };
@@ -206,9 +212,9 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   // fragments of the NEXT phase W of this wave are requested at the end (S waves: both images are complete; N waves: only
   // the delta bytes are).
   auto phaseX = [&](uint32_t dslot, int dma, const u32x4* dsrc, uint32_t rslot, uint32_t pslot, uint32_t sbuf, uint32_t wdslot, uint32_t wsbuf, WOps& wo) __attribute__((always_inline)) {
-    const uint32_t uEp = oRP + pslot * 8192u + (uint32_t)wave * 1024u;
-    const uint32_t uEs = oS16 + sbuf * 16384u + (uint32_t)wave * 2048u;
-    const uint32_t bX = base(aL8, oRD + dslot * 8192u);
+    const uint32_t uEp = oRP + pslot + (uint32_t)wave * 1024u;
+    const uint32_t uEs = oS16 + sbuf + (uint32_t)wave * 2048u;
+    const uint32_t bX = base(aL8, oRD + dslot);
     u32x4 wt[PARK > 0 ? PARK : 1];
     u32x4 bq[2];                                   // converted B operands: slot j uses bq[j & 1]
     u32x4 pw;                                      // the sixteen phase bytes of this lane
@@ -276,7 +282,7 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
   // W(kw) + E(ke): odst = where this wave's piece of the deltas of block ke goes (the dump for blocks outside the chunk).
   // xslot: ring slot of the block whose phase X this wave runs next (its first byte pieces are requested at the end).
   auto phaseW = [&](u32x4* odst, uint32_t sbuf, uint32_t wsbuf, int dma, const u32x4* dsrc, uint32_t rslot, uint32_t xslot, WOps& wo) __attribute__((always_inline)) {
-    const uint32_t uEs = oS16 + sbuf * 16384u + (uint32_t)wave * 2048u;
+    const uint32_t uEs = oS16 + sbuf + (uint32_t)wave * 2048u;
     float sv_even = 0.f;
     u32x4 ep_d;                        // outgoing fp8 deltas (every byte is written before the store: no initial value)
     asm volatile("" : "=v"(ep_d));
@@ -365,8 +371,8 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
     //   three operations of step k - 1 and P of step k => vmcnt(5).  P(k + 1), decoded at the end of X(k + 1), is older.
     //   S waves request the first byte pieces of X(k) at the end of the FIRST half of step k: D(k), requested in the second
     //   half of step k - 3; younger are P, store, D of steps k - 2 and k - 1 => vmcnt(6) at the first barrier.
-    for (int k = 0; k < AP; ++k) stageP(pP0 + (k < nblk ? k : nblk - 1) * blk_stride, (uint32_t)k);
-    for (int k = 0; k < AD; ++k) stageD(k < nblk ? pD0 + k * blk_stride : a.zeros, (uint32_t)k);
+    for (int k = 0; k < AP; ++k) stageP(pP0 + (k < nblk ? k : nblk - 1) * blk_stride, (uint32_t)k * 8192u);
+    for (int k = 0; k < AD; ++k) stageD(k < nblk ? pD0 + k * blk_stride : a.zeros, (uint32_t)k * 8192u);
     {   // zero images for the W phases of steps 0 and 1: ring slots 3 and 4 (blocks -2 and -1), the S16 buffers
       const u32x4 z = {0u, 0u, 0u, 0u};
       const uint32_t t16 = (uint32_t)(wave * 64 + lane) * 16u;
@@ -379,24 +385,25 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
     WOps wo = {0u, 0u, 0u};
     if (ROLE == 0) x_pre(0u);            // X(0)
     else {                               // the S waves' first W phase, W(-2): zero images
-      wo.b1 = base(aT1, w_uni_s(1u)); wo.b2 = base(aT2, w_uni_s(1u)); wb_load(wo, 0, fb[0]);
-      wo.a = base(aT8, w_uni_d(3u)); fa8[0] = wa_load(wo, 0, 0); fa8[1] = wa_load(wo, 0, 1);
+      wo.b1 = base(aT1, w_uni_s(16384u)); wo.b2 = base(aT2, w_uni_s(16384u)); wb_load(wo, 0, fb[0]);
+      wo.a = base(aT8, w_uni_d(3u * 8192u)); fa8[0] = wa_load(wo, 0, 0); fa8[1] = wa_load(wo, 0, 1);
     }
-    uint32_t i5 = 0, i4 = 0, i3 = 0;                                               // k mod 5, k mod 4, k mod 3
+    // Ring positions as BYTE OFFSETS in rotating scalar registers (a modulo or a compare-and-select per neighbour slot
+    // was twenty scalar instructions per step, and this loop pays for every instruction it issues: DESIGN.md section 4a):
+    // delta ring (5 slots of 8 KiB): blocks k-2 .. k+2;  sine buffers (3 of 16 KiB): blocks k-1, k, k+1
+    uint32_t d_m2 = 3u * 8192u, d_m1 = 4u * 8192u, d_0 = 0u, d_p1 = 8192u, d_p2 = 2u * 8192u;
+    uint32_t s_m1 = 2u * 16384u, s_0 = 0u, s_p1 = 16384u;
+    uint32_t pc = 0u;                                                              // (k mod 4) * 8 KiB: phase ring slot of block k
     const u32x4* pD = pD0 + AD * blk_stride;                                       // D(k + 3)
     const u32x4* pP = pP0 + (AP < nblk ? AP : nblk - 1) * blk_stride;              // P(min(k + 3, nblk - 1))
-    u32x4* pO = pO0;                                                               // deltas of block k
+    u32x4* pO = ROLE == 0 ? pO0 : pO0 - blk_stride;                                // deltas of block k (N waves) / k - 1 (S waves)
     u32x4* const dump = a.dump + wave * 64;
     // (the counted waits hold from step 0: what steps 0 to 2 read was requested above and has landed behind bar_all)
     for (int k = 0; k <= nblk + 1; ++k) {
-      const uint32_t i3p = i3 == 0u ? 2u : i3 - 1u;                       // S16 buffer of block k - 1
-      const uint32_t i5n = i5 == 4u ? 0u : i5 + 1u;                       // ring slot of D(k + 1)
-      const uint32_t i5p = i5 == 0u ? 4u : i5 - 1u;                       // ring slot of D(k - 1)
-      const uint32_t i5pp = i5p == 0u ? 4u : i5p - 1u;                    // ring slot of D(k - 2) = of D(k + 3)
-      const uint32_t i4p = (i4 + 3u) & 3u;                                // ring slot of P(k - 1) = of P(k + 3)
+      const uint32_t pm1 = (pc + 3u * 8192u) & 0x6000u;                  // phase ring slot of block k - 1 = of block k + 3
       const u32x4* const dsrc = k + AD < nblk ? pD : a.zeros;
-      u32x4* const o_n = k < nblk ? pO : dump;                            // E(k)    (N waves)
-      u32x4* const o_s = (k >= 1 && k <= nblk) ? pO - blk_stride : dump;  // E(k-1)  (S waves)
+      // E(k) of the N waves, E(k - 1) of the S waves: blocks outside the chunk go to the dump
+      u32x4* const odst = (unsigned)(ROLE == 0 ? k : k - 1) < (unsigned)nblk ? pO : dump;
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -404,8 +411,8 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b1 = __builtin_amdgcn_s_memtime();
 #endif
-      if (ROLE == 0) phaseX(i5, 2, pP, i4p, i4, i3, i5p, i3p, wo);                        // X(k) + sines(k); P(k+3); operands of W(k-1) requested
-      else phaseW(o_s, i3p, 0u, 2, pP, i4p, i5, wo);                                           // W(k-2) + E(k-1); P(k+3); bytes of X(k) requested
+      if (ROLE == 0) phaseX(d_0, 2, pP, pm1, pc, s_0, d_m1, s_m1, wo);                    // X(k) + sines(k); P(k+3); operands of W(k-1) requested
+      else phaseW(odst, s_m1, 0u, 2, pP, pm1, d_0, wo);                                   // W(k-2) + E(k-1); P(k+3); bytes of X(k) requested
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -413,17 +420,17 @@ __device__ __forceinline__ void bwd8h_body(const Bwd8Args& a, const int wave, co
 #ifdef SF_EXPERIMENT_STAMP
       const unsigned long long t_b3 = __builtin_amdgcn_s_memtime();
 #endif
-      if (ROLE == 0) phaseW(o_n, i3, i3p, 1, dsrc, i5pp, i5n, wo);                            // W(k-1) + E(k); D(k+3); bytes of X(k+1) requested
-      else phaseX(i5, 1, dsrc, i5pp, i4, i3, i5p, i3p, wo);                              // X(k) + sines(k); D(k+3); operands of W(k-1) requested
+      if (ROLE == 0) phaseW(odst, s_0, s_m1, 1, dsrc, d_m2, d_p1, wo);                    // W(k-1) + E(k); D(k+3); bytes of X(k+1) requested
+      else phaseX(d_0, 1, dsrc, d_m2, pc, s_0, d_m1, s_m1, wo);                           // X(k) + sines(k); D(k+3); operands of W(k-1) requested
 #ifdef SF_EXPERIMENT_STAMP
       { const unsigned long long t_b4 = __builtin_amdgcn_s_memtime(); st_bar += (t_b1 - t_b0) + (t_b3 - t_b2); st_x += t_b2 - t_b1; st_w += t_b4 - t_b3; st_n += 1; }
 #endif
 #ifdef SF_EXPERIMENT_STAMP2
       st2_n += 1;
 #endif
-      i5 = i5n;
-      i4 = (i4 + 1u) & 3u;
-      i3 = i3 == 2u ? 0u : i3 + 1u;
+      { const uint32_t t = d_m2; d_m2 = d_m1; d_m1 = d_0; d_0 = d_p1; d_p1 = d_p2; d_p2 = t; }
+      { const uint32_t t = s_m1; s_m1 = s_0; s_0 = s_p1; s_p1 = t; }
+      pc = (pc + 8192u) & 0x6000u;
       pD += blk_stride;
       pO += blk_stride;
       if (k + AP + 1 < nblk) pP += blk_stride;
