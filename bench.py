@@ -26,7 +26,12 @@ import torch  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak of MI355X (MI355X_MICROARCH.md chip table)
 
 
-KERNEL_SOURCES = ("siren_kernels.hip", "siren_wide.hip", "siren_fit.hip", "layout.h")
+def kernel_sources():
+    """Every source libsiren_fit.so is built from: all csrc/*.hip and csrc/*.h (a new kernel file is covered the day it
+    is added - round 2's list had missed the file that held the dominant kernel) + the C ABI header."""
+    import glob
+    csrc = os.path.join(ROOT, "implicit-image-compression_amd", "csrc")
+    return sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + [os.path.join(ROOT, "include", "siren_fit.h")]
 
 
 def kernel_source_hash():
@@ -34,8 +39,9 @@ def kernel_source_hash():
     kernels it was measured on (scripts/pmc_traffic_json.py records the same hash)."""
     import hashlib
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "implicit-image-compression_amd", "csrc", f), "rb").read())
+    for f in kernel_sources():
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
     return h.hexdigest()
 
 
@@ -119,6 +125,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--scratch", type=int, default=0, choices=[0, 8, 12, 16],
                     help="sf_config.scratch_format: 0 = auto (hidden <= 256, fp16: 8 = phase bytes + fp8 deltas from 2^20 pixels, 12 = phase bytes + 16-bit deltas below), 16 = round-1 format")
+    ap.add_argument("--no-formats", action="store_true", help="skip the by_scratch_format leg (5 warm-up + 10 timed steps per format after the headline region)")
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -247,6 +254,27 @@ def main():
                             "algorithmic_GBps": (v["bytes_per_launch"] * v["launches"] / (v["total_ms"] * 1e-3) / 1e9)
                             if v["total_ms"] > 0 else 0.0} for k, v in kern.items()},
         }
+        if world == 1 and not args.no_formats and args.hidden <= 256 and args.dtype == "f16":
+            # the same workload with every backward scratch format forced, timed by the same clock AFTER the headline
+            # region (5 warm-up + 10 timed steps each): the 16-bit-scratch throughput next to the fp8 one
+            del eng
+            torch.cuda.empty_cache()
+            out["by_scratch_format"] = {}
+            for fmt in (8, 12, 16):
+                e = SirenEngine(H, W, args.hidden, args.depth, compute_dtype=args.dtype, device=local_rank, chunk_pixels=args.chunk, scratch_format=fmt)
+                e.set_params(torch.cat([q.detach().reshape(-1) for q in init.parameters()]).to(dev))
+                e.set_coords(torch.linspace(0, 1, H).to(dev), torch.linspace(0, 1, W).to(dev))
+                e.set_target(img)
+                e.step([lr] * 5)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                e.step([lr] * 10)
+                torch.cuda.synchronize(dev)
+                dtf = (time.perf_counter() - t1) / 10
+                out["by_scratch_format"][str(fmt)] = {"value": H * W / dtf / 1e6, "unit": "Mpixel-iters/s", "ms_per_step": dtf * 1e3, "steps": 10, "warmup": 5}
+                e.close()
+                del e
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.hidden, args.depth, args.cpu_size)
         print(json.dumps(out))

@@ -17,6 +17,8 @@
 
 #include <map>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
@@ -53,9 +55,11 @@ static int fail(int code, const std::string& msg) {
 // adaptive part of the gradient pre-scale is applied by k_bwd8<LAST> (siren_s8.hip)
 static constexpr float kResScale = 1024.0f;
 
-enum KernelId { K_FWD = 0, K_BWD_HIDDEN, K_BWD_LAST, K_DW_FIRST, K_REDUCE, K_SSE, K_ADAM, K_IMAGES, K_COUNT };
+// (k_bwd_layer1: the backward of layer 1, whose input phases are re-derived from the coordinates - another kernel form than
+//  the hidden layers', so it gets its own line in the per-kernel report)
+enum KernelId { K_FWD = 0, K_BWD_HIDDEN, K_BWD_LAST, K_DW_FIRST, K_REDUCE, K_SSE, K_ADAM, K_IMAGES, K_BWD_L1, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_fwd",    "k_bwd_hidden", "k_bwd_last", "k_dw_first",
-                                            "k_reduce", "k_sse",        "k_adam",     "k_images"};
+                                            "k_reduce", "k_sse",        "k_adam",     "k_images", "k_bwd_layer1"};
 
 struct ProfRec {
   int id;
@@ -700,6 +704,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
 int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
   if (!h->have_coords) return fail(SF_ERR_STATE, "sf_set_coords has not been called");
   if ((train || want_sse) && !h->img) return fail(SF_ERR_STATE, "sf_set_target has not been called");
+  if (train && (!h->Pbuf || !h->Dbuf)) return fail(SF_ERR_STATE, "the handle has no backward scratch");   // (never a null store on the GPU)
   if (h->wide) return run_pass_wide(h, train, pred, want_sse);
   int rc = refresh_images(h);
   if (rc) return rc;
@@ -763,7 +768,10 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
       }
       ra.gW = h->grads + h->off_w[l]; ra.gb = h->grads + h->off_b[l];
       if (l > 0 && h->s8) {
-        const bool last = l == D - 1, p0 = l - 1 == 0;
+        // layer 1: with fp8 deltas at width 256 the pipeline forward also spills layer 0's phase bytes, so this layer runs the
+        // hidden-layer kernel (k_bwd8h) like the others; else the form that re-derives the layer-0 phases from the coordinates
+        static const bool l1_old = getenv("SIREN_FIT_BWD8H") && atoi(getenv("SIREN_FIT_BWD8H")) == 0;
+        const bool last = l == D - 1, l0_bytes = h->d8 && WD == 256 && fwd_is_pipe(h) && !l1_old, p0 = l - 1 == 0 && !(l0_bytes && !last);
         Bwd8Args ba;
         memset(&ba, 0, sizeof(ba));
         ba.D = last ? h->Dlast : h->Dbuf + (size_t)l * h->d_stride;
@@ -786,7 +794,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         ba.dbg = h->sse_part + h->n_sse;
 #endif
         const double rows = last ? h->cfg.out_features : WD;
-        Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 4.0 * rows * WD * n_pb * 32.0,
+        Launch L(h, last ? K_BWD_LAST : (p0 ? K_BWD_L1 : K_BWD_HIDDEN), 4.0 * rows * WD * n_pb * 32.0,
                  n_pb * 32.0 * ((last ? 32.0 : WD * (h->d8 ? 1.0 : 2.0)) + WD * (h->d8 ? 1.0 : 2.0) + (p0 ? 0.0 : WD * 1.0)));
         // hidden 256: the last-layer kernel keeps two workgroups per CU (its slab rows are 32 wide: the slab has room)
         int n_wg_l = n_wg;
@@ -818,7 +826,7 @@ int run_pass(sf_engine* h, bool train, float* pred, bool want_sse) {
         ba.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
         ba.sc_first = fa.sc_first;
         const double rows = last ? h->cfg.out_features : WD;
-        Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 4.0 * rows * WD * n_pb * 32.0,
+        Launch L(h, last ? K_BWD_LAST : (p0 ? K_BWD_L1 : K_BWD_HIDDEN), 4.0 * rows * WD * n_pb * 32.0,
                  n_pb * 32.0 * ((last ? 64.0 : WD * 2.0) + WD * (p0 ? 2.0 : 4.0)));
         rc = launch_bwd(h, last, p0, ba, n_wg);
         L.done();
@@ -876,13 +884,24 @@ int read_sse(sf_engine* h, double* out) {
 
 }  // namespace
 
+// No exception crosses the C ABI (include/siren_fit.h): every entry point is a function-try-block.  std::bad_alloc becomes
+// SF_ERR_NOMEM with a message short enough for the small-string buffer (no allocation on that path), anything else
+// SF_ERR_INVALID with the exception's text.
+static int fail_nomem() noexcept {
+  try { g_err.assign("out of memory"); } catch (...) {}
+  return SF_ERR_NOMEM;
+}
+#define SF_CATCH catch (const std::bad_alloc&) { return fail_nomem(); } \
+  catch (const std::exception& e) { try { return fail(SF_ERR_INVALID, std::string("unexpected exception: ") + e.what()); } catch (...) { return fail_nomem(); } } \
+  catch (...) { try { return fail(SF_ERR_INVALID, "unexpected exception"); } catch (...) { return fail_nomem(); } }
+
 extern "C" {
 
 int sf_abi_version(void) { return SF_ABI_VERSION; }
 const char* sf_last_error(void) { return g_err.c_str(); }
 
 static void set_scratch_strides(sf_engine* h);
-int sf_create(const sf_config* cfg, sf_handle** out) {
+int sf_create(const sf_config* cfg, sf_handle** out) try {
   if (!cfg || !out) return fail(SF_ERR_INVALID, "null argument");
   *out = nullptr;
   if (cfg->abi_version != SF_ABI_VERSION) return fail(SF_ERR_INVALID, "abi_version mismatch");
@@ -1016,9 +1035,9 @@ int sf_create(const sf_config* cfg, sf_handle** out) {
   hipMemsetAsync(h->v, 0, h->P * 4, h->stream);
   *out = h;
   return SF_OK;
-}
+} SF_CATCH
 
-int sf_destroy(sf_handle* h) {
+int sf_destroy(sf_handle* h) try {
   if (!h) return SF_OK;
   DevGuard dev_guard(h->cfg.device);
   if (h->stream || true) hipStreamSynchronize(h->stream);
@@ -1072,24 +1091,24 @@ int sf_destroy(sf_handle* h) {
   for (void* p : gptrs) if (p) hipFree(p);
   delete h;
   return SF_OK;
-}
+} SF_CATCH
 
-int sf_num_params(const sf_handle* h, int64_t* n) {
+int sf_num_params(const sf_handle* h, int64_t* n) try {
   if (!h || !n) return fail(SF_ERR_INVALID, "null argument");
   *n = h->P;
   return SF_OK;
-}
-int sf_scratch_format(const sf_handle* h, int32_t* format) {
+} SF_CATCH
+int sf_scratch_format(const sf_handle* h, int32_t* format) try {
   if (!h || !format) return fail(SF_ERR_INVALID, "null argument");
   *format = h->cfg.scratch_format;
   return SF_OK;
-}
-int sf_param_offset(const sf_handle* h, int32_t layer, int64_t* w, int64_t* b) {
+} SF_CATCH
+int sf_param_offset(const sf_handle* h, int32_t layer, int64_t* w, int64_t* b) try {
   if (!h || layer < 0 || layer >= h->D) return fail(SF_ERR_INVALID, "bad layer");
   if (w) *w = h->off_w[layer];
   if (b) *b = h->off_b[layer];
   return SF_OK;
-}
+} SF_CATCH
 
 static int copy_in(sf_engine* h, float* dst, const float* src) {
   if (!h || !src) return fail(SF_ERR_INVALID, "null argument");
@@ -1103,14 +1122,14 @@ static int copy_out(sf_engine* h, float* dst, const float* src) {
   HIPCHK(hipMemcpyAsync(dst, src, h->P * 4, hipMemcpyDeviceToDevice, h->stream));
   return SF_OK;
 }
-int sf_set_params(sf_handle* h, const float* p) {
+int sf_set_params(sf_handle* h, const float* p) try {
   int rc = copy_in(h, h ? h->params : nullptr, p);
   if (!rc) h->images_dirty = true;
   return rc;
-}
-int sf_get_params(sf_handle* h, float* p) { return copy_out(h, p, h ? h->params : nullptr); }
-int sf_get_grads(sf_handle* h, float* p) { return copy_out(h, p, h ? h->grads : nullptr); }
-int sf_set_grads(sf_handle* h, const float* p) { return copy_in(h, h ? h->grads : nullptr, p); }
+} SF_CATCH
+int sf_get_params(sf_handle* h, float* p) try { return copy_out(h, p, h ? h->params : nullptr); } SF_CATCH
+int sf_get_grads(sf_handle* h, float* p) try { return copy_out(h, p, h ? h->grads : nullptr); } SF_CATCH
+int sf_set_grads(sf_handle* h, const float* p) try { return copy_in(h, h ? h->grads : nullptr, p); } SF_CATCH
 // layer strides of the phase / delta scratch for the handle's current format
 static void set_scratch_strides(sf_engine* h) {
   const long chunk = h->chunk_px;
@@ -1120,22 +1139,32 @@ static void set_scratch_strides(sf_engine* h) {
 }
 // An auto-format handle that receives a mask leaves the 8-bit scratch: fp8 deltas under one scale per chunk underflow in
 // a 90 %-sparse network, and topology updates rank small gradients that phase bytes blur.
+// (the new buffers are allocated BEFORE anything of the handle changes: a failed hipMalloc leaves the handle exactly as it
+//  was - format, strides and scratch - and returns SF_ERR_NOMEM)
 static int switch_scratch_format(sf_engine* h, int fmt) {
   hipStreamSynchronize(h->stream);
-  if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+  const sf_config cfg0 = h->cfg;
+  const bool s8_0 = h->s8, d8_0 = h->d8;
   h->cfg.scratch_format = fmt;
   h->s8 = fmt == 8 || fmt == 12;
   h->d8 = fmt == 8;
   set_scratch_strides(h);
+  u32x4 *newP = nullptr, *newD = nullptr;
+  if (hipMalloc((void**)&newP, (size_t)(h->D - 1) * h->p_stride * 16) != hipSuccess ||
+      hipMalloc((void**)&newD, (size_t)(h->D - 1) * h->d_stride * 16) != hipSuccess) {
+    if (newP) hipFree(newP);
+    (void)hipGetLastError();
+    h->cfg = cfg0; h->s8 = s8_0; h->d8 = d8_0;
+    set_scratch_strides(h);
+    return fail(SF_ERR_NOMEM, "hipMalloc failed while moving the scratch to format 16 (the handle keeps its format)");
+  }
+  if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
   if (h->Pbuf) hipFree(h->Pbuf);
   if (h->Dbuf) hipFree(h->Dbuf);
-  h->Pbuf = nullptr; h->Dbuf = nullptr;
-  if (hipMalloc((void**)&h->Pbuf, (size_t)(h->D - 1) * h->p_stride * 16) != hipSuccess ||
-      hipMalloc((void**)&h->Dbuf, (size_t)(h->D - 1) * h->d_stride * 16) != hipSuccess)
-    return fail(SF_ERR_NOMEM, "hipMalloc failed while moving the scratch to format 16");
+  h->Pbuf = newP; h->Dbuf = newD;
   return SF_OK;
 }
-int sf_set_masks(sf_handle* h, const float* p) {
+int sf_set_masks(sf_handle* h, const float* p) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   if (!p) { h->has_mask = false; return SF_OK; }
@@ -1146,24 +1175,24 @@ int sf_set_masks(sf_handle* h, const float* p) {
   int rc = copy_in(h, h->mask, p);
   if (!rc) h->has_mask = true;
   return rc;
-}
-int sf_get_adam_state(sf_handle* h, float* m, float* v, int64_t* step) {
+} SF_CATCH
+int sf_get_adam_state(sf_handle* h, float* m, float* v, int64_t* step) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   if (m) { int rc = copy_out(h, m, h->m); if (rc) return rc; }
   if (v) { int rc = copy_out(h, v, h->v); if (rc) return rc; }
   if (step) *step = h->step;
   return SF_OK;
-}
-int sf_set_adam_state(sf_handle* h, const float* m, const float* v, int64_t step) {
+} SF_CATCH
+int sf_set_adam_state(sf_handle* h, const float* m, const float* v, int64_t step) try {
   if (!h || step < 0) return fail(SF_ERR_INVALID, "bad argument");
   DevGuard dev_guard(h->cfg.device);
   if (m) { int rc = copy_in(h, h->m, m); if (rc) return rc; }
   if (v) { int rc = copy_in(h, h->v, v); if (rc) return rc; }
   h->step = step;
   return SF_OK;
-}
-int sf_state_ptr(sf_handle* h, int32_t which, float** p) {
+} SF_CATCH
+int sf_state_ptr(sf_handle* h, int32_t which, float** p) try {
   if (!h || !p) return fail(SF_ERR_INVALID, "null argument");
   switch (which) {
     case 0: *p = h->params; return SF_OK;
@@ -1173,15 +1202,15 @@ int sf_state_ptr(sf_handle* h, int32_t which, float** p) {
     case 4: *p = h->mask; return SF_OK;
   }
   return fail(SF_ERR_INVALID, "bad state selector");
-}
+} SF_CATCH
 
-int sf_sse_ptr(sf_handle* h, double** p) {
+int sf_sse_ptr(sf_handle* h, double** p) try {
   if (!h || !p) return fail(SF_ERR_INVALID, "null argument");
   *p = h->sse_dev;
   return SF_OK;
-}
+} SF_CATCH
 
-int sf_debug_scratch(sf_handle* h, int32_t which, void** p, int64_t* bytes) {
+int sf_debug_scratch(sf_handle* h, int32_t which, void** p, int64_t* bytes) try {
   if (!h || !p || !bytes) return fail(SF_ERR_INVALID, "null argument");
   const int D = h->D;
   switch (which) {
@@ -1191,15 +1220,15 @@ int sf_debug_scratch(sf_handle* h, int32_t which, void** p, int64_t* bytes) {
     case 3: { const size_t sw = h->WD > 256 ? 256 : h->WD; *p = h->slab; *bytes = (int64_t)h->dw_wg * (sw * sw + sw) * 4; return SF_OK; }
   }
   return fail(SF_ERR_INVALID, "bad scratch selector");
-}
+} SF_CATCH
 
-int sf_params_changed(sf_handle* h) {
+int sf_params_changed(sf_handle* h) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   h->images_dirty = true;
   return SF_OK;
-}
+} SF_CATCH
 
-int sf_set_coords(sf_handle* h, const float* rows, const float* cols) {
+int sf_set_coords(sf_handle* h, const float* rows, const float* cols) try {
   if (!h || !rows || !cols) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   HIPCHK(hipMemcpyAsync(h->gh, rows, (size_t)h->cfg.height * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -1224,14 +1253,14 @@ int sf_set_coords(sf_handle* h, const float* rows, const float* cols) {
   }
   h->have_coords = true;
   return SF_OK;
-}
-int sf_set_target(sf_handle* h, const float* img) {
+} SF_CATCH
+int sf_set_target(sf_handle* h, const float* img) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   h->img = img;
   return SF_OK;
-}
+} SF_CATCH
 
-int sf_forward(sf_handle* h, float* pred, double* sse_out) {
+int sf_forward(sf_handle* h, float* pred, double* sse_out) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   const bool want = sse_out != nullptr;
@@ -1241,18 +1270,18 @@ int sf_forward(sf_handle* h, float* pred, double* sse_out) {
   if (rc) return rc;
   if (want) return read_sse(h, sse_out);
   return SF_OK;
-}
+} SF_CATCH
 
-int sf_forward_backward(sf_handle* h, double* sse_out) {
+int sf_forward_backward(sf_handle* h, double* sse_out) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   int rc = run_pass(h, true, nullptr, true);
   if (rc) return rc;
   if (sse_out) return read_sse(h, sse_out);
   return SF_OK;
-}
+} SF_CATCH
 
-int sf_adam_step(sf_handle* h, float lr) {
+int sf_adam_step(sf_handle* h, float lr) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   h->step += 1;
@@ -1275,7 +1304,7 @@ int sf_adam_step(sf_handle* h, float lr) {
   HIPCHK(hipGetLastError());
   h->images_dirty = true;
   return refresh_images(h);
-}
+} SF_CATCH
 
 
 // ---- graph replay -----------------------------------------------------------------------------------------
@@ -1355,7 +1384,7 @@ static int step_replay(sf_engine* h, const float* lr, int n, float* loss_out) {
   return SF_OK;
 }
 
-int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) {
+int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) try {
   if (!h || !lr || n_steps < 0) return fail(SF_ERR_INVALID, "bad argument");
   DevGuard dev_guard(h->cfg.device);
   if (!h->have_coords) return fail(SF_ERR_STATE, "sf_set_coords has not been called");
@@ -1391,36 +1420,36 @@ int sf_step(sf_handle* h, const float* lr, int32_t n_steps, float* loss_out) {
     if (rc) return rc;
   }
   return SF_OK;
-}
+} SF_CATCH
 
-int sf_set_graph_replay(sf_handle* h, int32_t on) {
+int sf_set_graph_replay(sf_handle* h, int32_t on) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   h->want_replay = on != 0;
   return SF_OK;
-}
+} SF_CATCH
 
-int sf_profile_enable(sf_handle* h, int32_t on) {
+int sf_profile_enable(sf_handle* h, int32_t on) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   if (!on) { int rc = prof_flush(h); if (rc) return rc; }
   h->prof = on != 0;
   return SF_OK;
-}
-int sf_profile_reset(sf_handle* h) {
+} SF_CATCH
+int sf_profile_reset(sf_handle* h) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   int rc = prof_flush(h);
   if (rc) return rc;
   for (int i = 0; i < K_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; h->prof_flops[i] = 0; h->prof_bytes[i] = 0; }
   return SF_OK;
-}
-int sf_profile_num_kernels(const sf_handle* h, int32_t* n) {
+} SF_CATCH
+int sf_profile_num_kernels(const sf_handle* h, int32_t* n) try {
   if (!h || !n) return fail(SF_ERR_INVALID, "null argument");
   *n = K_COUNT;
   return SF_OK;
-}
+} SF_CATCH
 int sf_profile_get(sf_handle* h, int32_t idx, const char** name, double* total_ms, int64_t* launches,
-                   double* flops_per_launch, double* bytes_per_launch) {
+                   double* flops_per_launch, double* bytes_per_launch) try {
   if (!h || idx < 0 || idx >= K_COUNT) return fail(SF_ERR_INVALID, "bad kernel index");
   DevGuard dev_guard(h->cfg.device);
   int rc = prof_flush(h);
@@ -1432,6 +1461,14 @@ int sf_profile_get(sf_handle* h, int32_t idx, const char** name, double* total_m
   if (flops_per_launch) *flops_per_launch = h->prof_flops[idx] / nl;
   if (bytes_per_launch) *bytes_per_launch = h->prof_bytes[idx] / nl;
   return SF_OK;
-}
+} SF_CATCH
+
+/* test aid: throws inside the boundary on purpose (0: std::bad_alloc, 1: std::runtime_error, 2: a non-std exception) */
+int sf_debug_throw(int32_t kind) try {
+  if (kind == 0) throw std::bad_alloc();
+  if (kind == 1) throw std::runtime_error("sf_debug_throw");
+  if (kind == 2) throw 42;
+  return SF_OK;
+} SF_CATCH
 
 }  // extern "C"

@@ -675,16 +675,25 @@ __global__ __launch_bounds__(512) void k_fwd_pipe(FwdArgs a) {
     for (int nt = 1; nt < NT; ++nt) {
       const f32x16 zn = l0_tile(nt);
       if (nt <= 2) { x1_piece(2 * nt - 2); x1_piece(2 * nt - 1); } else x1_piece(nt + 1);
+      uint32_t pb8[4];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         uint32_t w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          w[j] = OP::pack2(__builtin_amdgcn_sinf(z[8 * q + 2 * j]), __builtin_amdgcn_sinf(z[8 * q + 2 * j + 1]));
+          const float s0 = __builtin_amdgcn_sinf(z[8 * q + 2 * j]), s1 = __builtin_amdgcn_sinf(z[8 * q + 2 * j + 1]);
+          if constexpr (TRAIN && S8) {
+            // phase bytes of layer 0 (round 3): the backward of layer 1 reads them like any hidden layer's, so it runs
+            // the hidden-layer kernel (k_bwd8h) instead of the form that re-derives these phases from the coordinates
+            if (j & 1) { phase_byte<2>(pb8[2 * q + (j >> 1)], z[8 * q + 2 * j], s0); phase_byte<3>(pb8[2 * q + (j >> 1)], z[8 * q + 2 * j + 1], s1); }
+            else { phase_byte<0>(pb8[2 * q + (j >> 1)], z[8 * q + 2 * j], s0); phase_byte<1>(pb8[2 * q + (j >> 1)], z[8 * q + 2 * j + 1], s1); }
+          }
+          w[j] = OP::pack2(s0, s1);
           asm volatile("" : "+v"(w[j]));   // pinned to this tile (MachineSink would carry the phases down to their first use)
         }
         Ba[2 * (nt - 1) + q] = u32x4{w[0], w[1], w[2], w[3]};
       }
+      if constexpr (TRAIN && S8) store_stream(a.P + ((size_t)pb * NT + (nt - 1)) * 64 + lane, u32x4{pb8[0], pb8[1], pb8[2], pb8[3]});
       slot_end();
       z = zn;
     }

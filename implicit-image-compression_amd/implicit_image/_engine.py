@@ -58,6 +58,7 @@ def load_library():
         "sf_state_ptr": [H, C.c_int32, C.POINTER(C.c_void_p)],
         "sf_sse_ptr": [H, C.POINTER(C.c_void_p)],
         "sf_debug_scratch": [H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(I64)],
+        "sf_debug_throw": [C.c_int32],
         "sf_params_changed": [H],
         "sf_set_coords": [H, F, F], "sf_set_target": [H, F],
         "sf_forward": [H, F, C.POINTER(C.c_double)],

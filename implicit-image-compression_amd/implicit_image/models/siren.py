@@ -82,7 +82,9 @@ class Siren(nn.Module):
     # ---- engine binding -------------------------------------------------------------------
     def set_scratch_format(self, fmt: int):
         """sf_config.scratch_format of the engine (0 auto / 8 / 12 / 16); a live engine of another format is rebuilt on
-        the next pass (parameters and optimiser moments are carried over by the rebind)."""
+        the next pass: engine() carries the parameters, the Adam moments and step count (sf_get/set_adam_state) and the
+        masks over to the new handle and rebinds every EngineAdam created on this model, so a switch in the middle of a
+        fit neither resets the optimiser nor leaves `optimizer.state[p]` pointing at freed device memory."""
         if self.cfg["scratch_format"] != int(fmt):
             self.cfg["scratch_format"] = int(fmt)
 
@@ -110,7 +112,12 @@ class Siren(nn.Module):
         key = (H, w, row_begin, row_end, grid.device.index, self._adam, self.cfg["scratch_format"])
         if self._engine is None or self._engine_key != key:
             c = self.cfg
+            carry = None
             if self._engine is not None:
+                old = self._engine
+                m, v, st = old.get_adam_state()
+                masks = old.view("masks").clone() if getattr(self, "_has_engine_mask", False) else None
+                carry = (m, v, st, masks, old.num_params, (old.height, old.width, old.row_begin, old.row_end))
                 self._unbind()
             self._engine = SirenEngine(H, w, self._engine_width, c["depth"], c["first_omega_0"], c["hidden_omega_0"],
                                        c["outermost_linear"], c["output_size"], c["compute_dtype"],
@@ -118,6 +125,19 @@ class Siren(nn.Module):
                                        chunk_pixels=c["chunk_pixels"], betas=self._adam[0], eps=self._adam[1],
                                        scratch_format=c["scratch_format"])
             self._engine_key, self._grid_key, self._target_key = key, None, None
+            new = self._engine
+            if carry is not None and carry[4] == new.num_params and carry[5] == (new.height, new.width, new.row_begin, new.row_end):
+                # same fit on a re-created handle (another scratch format / Adam hyper-parameters): the optimiser goes along
+                new.set_adam_state(carry[0], carry[1], carry[2])
+                if carry[3] is not None:
+                    new.set_masks(carry[3])
+            else:
+                self._has_engine_mask = False
+            for opt in list(getattr(self, "_engine_optims", ())):
+                opt._bound = None
+                if not self._padded:
+                    self._sync_to_engine()
+                    opt._bind_state(new)
         eng = self._engine
         gkey = (grid.data_ptr(), tuple(grid.shape))
         if self._grid_key != gkey:
@@ -201,6 +221,7 @@ class Siren(nn.Module):
     def set_engine_masks(self, flat_logical: torch.Tensor):
         """0/1 mask per logical parameter element -> engine (scattered into the wider layout when padded)."""
         eng = self._engine
+        self._has_engine_mask = True
         if self._padded:
             full = torch.zeros(eng.num_params, device=eng.device)
             full[self._padded_index(eng.device)] = flat_logical.to(eng.device).float()

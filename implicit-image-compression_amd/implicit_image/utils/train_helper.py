@@ -38,6 +38,10 @@ class EngineAdam(Optimizer):
         model.set_adam_hparams(tuple(float(b) for b in betas), float(eps))   # sf_config.beta1/beta2/eps of the engine
         super().__init__(model._param_list(), dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self._bound = None
+        import weakref
+        if not hasattr(model, "_engine_optims"):
+            model._engine_optims = weakref.WeakSet()     # Siren.engine() rebinds these when it re-creates the handle
+        model._engine_optims.add(self)
 
     def _bind_state(self, eng):
         if getattr(self.model, "_padded", False):     # padded widths: logical copies, refreshed after every step
@@ -54,7 +58,7 @@ class EngineAdam(Optimizer):
         for p in self.model._param_list():
             n = p.numel()
             st = self.state[p]
-            st["step"] = torch.tensor(0.0)
+            st.setdefault("step", torch.tensor(0.0))
             st["exp_avg"] = m[off:off + n].view(p.shape)
             st["exp_avg_sq"] = v[off:off + n].view(p.shape)
             off += n
@@ -126,8 +130,10 @@ def setup_mask(model: Module, optim: Optimizer, masking_cfg=None) -> Masking:
     # PSNR of the config-4 fixture moves by +0.19 dB (criterion: 0.05; with unorm16 phases it holds).  Masked fits
     # therefore run with unorm16 phases unless the model was built with an explicit format.  (Exact-zero gradients -
     # ties the sort resolves arbitrarily - no longer occur with phase bytes: kPhaseEps in siren_kernels.hip.)
-    if hasattr(model, "set_scratch_format") and model.cfg.get("scratch_format", 0) == 0 \
-            and _cfg_get(masking_cfg, "growth_mode") in ("absolute-gradient", "momentum"):
+    # ONE rule, the engine's own (sf_set_masks moves every auto handle to 16 when a mask is set): an auto model is created
+    # with format 16 here, so the engine never allocates the 8-bit scratch first only to free it at the first mask push.
+    # An EXPLICIT 8 or 12 stays as given on both sides (topology updates with it are unsupported: DESIGN.md section 2).
+    if hasattr(model, "set_scratch_format") and model.cfg.get("scratch_format", 0) == 0:
         model.set_scratch_format(16)
     model.train()
     mask.add_module(model)

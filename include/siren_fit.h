@@ -111,6 +111,9 @@ int sf_sse_ptr(sf_handle* h, double** dev_ptr);
 /* test / debugging aid: device address and size in bytes of an engine scratch tensor of the last pass.
  * which: 0 phases (all layers, layer stride = bytes / (depth-1)), 1 deltas, 2 dL/dout, 3 per-workgroup slabs */
 int sf_debug_scratch(sf_handle* h, int32_t which, void** dev_ptr, int64_t* bytes);
+/* test aid for the "never throws" promise above: raises inside the library on purpose (0: std::bad_alloc -> SF_ERR_NOMEM,
+ * 1: std::runtime_error, 2: a non-std exception -> SF_ERR_INVALID); every entry point is a function-try-block */
+int sf_debug_throw(int32_t kind);
 /* tell the engine that the caller wrote the parameters through the sf_state_ptr(…,0) view */
 int sf_params_changed(sf_handle* h);
 

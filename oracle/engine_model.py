@@ -117,6 +117,7 @@ def _loss_and_grads_s8(params, grid, img, first_omega_0, hidden_omega_0, n_total
     W0, b0 = params[0], params[1]
     z = torch.addcmul(torch.addcmul(b0, x[:, 0:1], W0[:, 0]), x[:, 1:2], W0[:, 1])
     t = z * torch.tensor(first_omega_0 / TWO_PI, dtype=torch.float32)
+    t0 = t
     ph0 = t - torch.floor(t)
     hs = torch.tensor(hidden_omega_0 / TWO_PI, dtype=torch.float32)
     q = [None]
@@ -139,8 +140,14 @@ def _loss_and_grads_s8(params, grid, img, first_omega_0, hidden_omega_0, n_total
     sc_last = torch.tensor(1.0 / (S0 * nv), dtype=torch.float32)
     grads = [None] * (2 * depth)
     delta = dlast
+    # round 3: at hidden 256 / depth >= 3 (k_fwd_pipe + k_bwd8h) layer 0's phases are spilled as bytes too and the backward
+    # of layer 1 decodes them like any hidden layer's; elsewhere they are re-derived from the coordinates (fp32)
+    l0_bytes = params[0].shape[0] == 256 and depth >= 3
     for l in range(L, 0, -1):
-        ph = ph0 if l - 1 == 0 else q[l - 1] * (1.0 / 256.0) + PHASE_EPS
+        if l - 1 == 0:
+            ph = _phase_q8(t0) * (1.0 / 256.0) + PHASE_EPS if (l0_bytes and l != L) else ph0
+        else:
+            ph = q[l - 1] * (1.0 / 256.0) + PHASE_EPS
         act = _rt(torch.sin(TWO_PI * ph.double()).float(), "f16")
         sc = sc_last if l == L else sc_hidden
         grads[2 * l] = (delta.t() @ act) * sc

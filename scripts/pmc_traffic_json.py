@@ -18,9 +18,11 @@ from bench import kernel_source_hash  # noqa: E402
 NAMES = [("k_fwd<256", "k_fwd"), ("k_fwd_pipe<", "k_fwd"), ("k_bwd<32, 256", "k_bwd_last"), ("k_bwd<256, 256, 2, 4", "k_bwd_hidden"),
          ("k_bwd<256, 256, 2, 2", "k_bwd_hidden_layer1"), ("k_dw0<256", "k_dw_first"), ("k_dw0_8<256", "k_dw_first"),
          # scratch formats 12 / 8 (siren_s8.hip): LAST, hidden (P0 = false) and layer-1 (P0 = true) forms
-         ("k_bwd8<32, 256", "k_bwd_last"), ("k_bwd8<256, 256, 2, 4, false, false", "k_bwd_hidden"),
+         ("k_bwd8<32, 256", "k_bwd_last"), ("k_bwd8<256, 256, 2, 4, false, false", "k_bwd_hidden_r2"),
          ("k_bwd8<256, 256, 2, 2, false, false", "k_bwd_hidden"), ("k_bwd8<256, 256, 2, 4, false, true", "k_bwd_hidden_layer1"),
-         ("k_bwd8<256, 256, 2, 2, false, true", "k_bwd_hidden_layer1")]
+         ("k_bwd8<256, 256, 2, 2, false, true", "k_bwd_hidden_layer1"),
+         # round 3: the slot-per-MFMA pipeline of the hidden layers (siren_s8h.hip)
+         ("k_bwd8h<", "k_bwd_hidden")]
 
 
 def main():

@@ -101,6 +101,11 @@ def main():
         two_runs(th, siren, grid, img, 64, 4, 4000, None, "long_64x4_256")
         img, grid = nonsmooth_image(128, 128), data.get_grid(128, 128)
         two_runs(th, siren, grid, img, 128, 6, 4000, None, "long_128x6_128")
+    if "nonsmooth_long" in what:
+        # the same content annealed over 1000 steps (StepLR(200, 0.5)): at 200 steps this image is still in its fast
+        # descent (loss falls 6x between steps 10 and 40) and a 1e-3 perturbation of the gradients picks another basin
+        img, grid = nonsmooth_image(256, 256), data.get_grid(256, 256)
+        two_runs(th, siren, grid, img, 256, 8, 1000, 200, "plateau_ns_256x8_256_1000")
     if "nonsmooth" in what:
         S = int(os.environ.get("NS_SIZE", "256"))
         threads = tuple(int(t) for t in os.environ.get("NS_THREADS", "8,2").split(","))

@@ -1,6 +1,8 @@
 """CPU-side checks: the C-ABI library loads and exports every symbol include/siren_fit.h declares;
 the host mirror reproduces the reference's init, ERK masks, prune/grow step, cosine decay and the
 full RigL topology trace bit-exactly (index paths).  No compute calls into the library here."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -53,6 +55,23 @@ def test_create_rejects_bad_config_without_gpu():
     cfg.abi_version = 99
     assert lib.sf_create(C.byref(cfg), C.byref(h)) == -1
     assert lib.sf_create(None, C.byref(h)) == -1
+
+
+def test_no_exception_crosses_the_c_abi():
+    """include/siren_fit.h promises "never throws": every entry point is a function-try-block.
+    sf_debug_throw raises inside the library on purpose; what arrives is a status code and a message, and the process
+    (a ctypes caller cannot catch a C++ exception) is still alive afterwards."""
+    lib = _engine.load_library()
+    assert lib.sf_debug_throw(0) == -5 and b"out of memory" in lib.sf_last_error()          # std::bad_alloc -> SF_ERR_NOMEM
+    assert lib.sf_debug_throw(1) == -1 and b"sf_debug_throw" in lib.sf_last_error()         # std::runtime_error -> SF_ERR_INVALID
+    assert lib.sf_debug_throw(2) == -1 and b"unexpected exception" in lib.sf_last_error()   # anything else
+    assert lib.sf_debug_throw(3) == 0
+    import re
+    src = open(os.path.join(os.path.dirname(_engine._LIB_PATH), "siren_fit.hip")).read()
+    body = src[src.index('extern "C" {'):src.index('}  // extern "C"')]
+    entry = re.findall(r"^(?:int|const char\*) (sf_\w+)\(", body, flags=re.M)
+    guarded = re.findall(r"^int (sf_\w+)\([^{]*\) try \{", body, flags=re.M)
+    assert set(entry) - set(guarded) <= {"sf_abi_version", "sf_last_error"}, set(entry) - set(guarded)
 
 
 def test_model_init_matches_reference(golden):

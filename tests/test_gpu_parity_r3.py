@@ -1,0 +1,269 @@
+"""Round-3 GPU parity tests (run with `-m gpu` on an MI355X): the evidence under the headline configuration widened to
+non-smooth image content, to the reference's real optimiser schedule, to a long horizon at small residual, and to the
+sparse (masked) wide path of BASELINE config 5.  Fixtures: tests/golden/make_golden_r3.py (the REAL reference, run in the
+build container; only data travels).  The images are regenerated from oracle formulas and pinned by the sha256 the
+fixture stores.
+
+Tolerances (stated where used):
+  PSNR after equal steps   : |dPSNR| <= 0.05 dB  (BASELINE.json north star) wherever the reference's own 8- vs 2-thread
+                             spread, stored in the fixture, is below it; where the reference's own runs differ by more
+                             (long un-annealed or very-high-PSNR fits) the bound is the reference's spread + 0.05 dB and the
+                             docstring says so
+  masks / index paths      : bit-exact
+"""
+import hashlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import siren_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+FORMATS = (16, 12, 8)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _engine(H, W, hidden, depth, dtype="f16", params=None, img=None, **kw):
+    from implicit_image._engine import SirenEngine
+    eng = SirenEngine(H, W, hidden, depth, compute_dtype=dtype, **kw)
+    gh, gw = so.grid_vectors(H, W)
+    eng.set_coords(gh.cuda(), gw.cuda())
+    if params is not None:
+        eng.set_params(torch.tensor(so.flatten(params)).cuda())
+    if img is not None:
+        eng.set_target(img[eng.row_begin:eng.row_end].contiguous().cuda())
+    return eng
+
+
+def _fit(d, fmt, img, lr_of_step):
+    hidden, depth, H, W, steps = int(d["hidden"]), int(d["depth"]), int(d["height"]), int(d["width"]), int(d["steps"])
+    assert _sha(img.numpy()) == str(d["img_sha256"])                     # the image the reference was run on
+    p = so.siren_init(hidden, depth, seed=0)
+    assert np.array_equal(so.flatten(p)[:64], d["init_head"])            # the fixture's seed-0 init
+    eng = _engine(H, W, hidden, depth, "f16", p, img, scratch_format=fmt)
+    losses = np.array(eng.step([lr_of_step(t) for t in range(steps)], want_loss=True))
+    _, sse = eng.forward(want_pred=False)
+    return 10 * math.log10(3 * H * W / sse), losses
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_psnr_parity_on_non_smooth_content(golden, fmt):
+    """the metric model (SIREN 256x8), 200 annealed steps, on an image with step edges, regions
+    clamped at exactly 0 and 1, a one-pixel checkerboard and 0.1 % outlier pixels (oracle.nonsmooth_image) - the content
+    a per-chunk fp8 delta scale and a +-448 saturation are sensitive to.  Reference: 21.2742 dB, its own 8- vs 2-thread
+    spread 0.0000 dB.  |dPSNR| <= 0.05 dB for every fp16 scratch format."""
+    d = golden("plateau_ns_256x8_256")
+    assert float(d["psnr_spread"]) <= 0.01
+    lr_step = int(d["lr_step"])
+    psnr, losses = _fit(d, fmt, so.nonsmooth_image(256, 256), lambda t: 3e-4 * 0.5 ** (t // lr_step))
+    assert abs(psnr - float(d["psnr"])) <= 0.05, (psnr, float(d["psnr"]))
+    assert np.max(np.abs(losses[:4] - d["losses"][:4]) / d["losses"][:4]) <= 3e-3
+    assert abs(losses[-1] / d["losses"][-1] - 1) <= 2e-2
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_psnr_parity_under_the_reference_schedule_4000_steps(golden, fmt):
+    """the reference's REAL optimiser schedule - get_optimizer_lr_scheduler's StepLR(2000, 0.5)
+    (train_helper.py:80-84) - over 4000 steps, SIREN 64x4 on the 256 x 256 non-smooth image.  Reference: 20.9764 dB (8
+    threads) / 20.9797 dB (2 threads): its own spread is 0.0033 dB, so the 0.05 dB criterion is meaningful here.  The
+    mean loss of the last 200 steps (a smoother statistic than one step's PSNR) must agree to 1 %."""
+    d = golden("long_64x4_256")
+    assert float(d["psnr_spread"]) <= 0.01
+    psnr, losses = _fit(d, fmt, so.nonsmooth_image(256, 256), lambda t: so.step_lr(3e-4, t))
+    assert abs(psnr - float(d["psnr"])) <= 0.05, (psnr, float(d["psnr"]), float(d["psnr_2threads"]))
+    assert abs(losses[-200:].mean() / float(d["tail_loss"]) - 1) <= 1e-2
+    assert np.max(np.abs(losses[:50] - d["losses"][:50]) / d["losses"][:50]) <= 3e-3
+
+
+def test_long_unannealed_fit_at_high_psnr_is_chaotic_in_the_reference_too(golden):
+    """The same schedule at 128x6 on 128 x 128: the reference ends at 49.68 dB with 8 threads and at 55.18 dB with 2 - its
+    own summation order moves the end PSNR by 5.5 dB, so no 0.05 dB statement can be made on such a run (which is why the
+    PSNR fixtures are annealed).  What is compared: the first 50 steps of the loss curve, the mean loss of the last 200
+    steps (reference: 6.25e-6 / 6.59e-6) within a factor 1.5, and an end PSNR inside the reference's own range +- 3 dB."""
+    d = golden("long_128x6_128")
+    assert float(d["psnr_spread"]) > 1.0
+    psnr, losses = _fit(d, 0, so.nonsmooth_image(128, 128), lambda t: so.step_lr(3e-4, t))
+    lo, hi = sorted((float(d["psnr"]), float(d["psnr_2threads"])))
+    assert lo - 3.0 <= psnr <= hi + 3.0, (psnr, lo, hi)
+    tail = losses[-200:].mean()
+    assert min(float(d["tail_loss"]), float(d["tail_loss_2threads"])) / 1.5 <= tail <= max(float(d["tail_loss"]), float(d["tail_loss_2threads"])) * 1.5
+    assert np.max(np.abs(losses[:50] - d["losses"][:50]) / d["losses"][:50]) <= 3e-3
+
+
+def test_config1_reference_spread_and_annealed_parity(golden):
+    """VERDICT r2 W1 / item 2(iii).  BASELINE config 1 (64x4 on 256 x 256, 1000 un-annealed steps): the reference's own 8-
+    vs 2-thread end PSNR differs by 0.0026 dB (hot_64x4_256_spread.npz), i.e. the 0.05 dB assertion of
+    test_loss_curve_tracks_oracle_then_psnr_parity_config1 is meaningful against the reference's summation-order noise -
+    and the annealed variant of the same run (StepLR(200, 0.5): 30.9104 dB, spread 0.0000) pins it on a settled value."""
+    s = golden("hot_64x4_256_spread")
+    assert float(s["psnr_spread"]) <= 0.01 and abs(float(s["psnr_8threads"]) - float(s["psnr_fixture"])) <= 1e-6
+    d = golden("hot_64x4_256_annealed")
+    assert float(d["psnr_spread"]) <= 0.01
+    lr_step = int(d["lr_step"])
+    psnr, losses = _fit(d, 0, so.synthetic_image(256, 256), lambda t: 3e-4 * 0.5 ** (t // lr_step))
+    assert abs(psnr - float(d["psnr"])) <= 0.05, (psnr, float(d["psnr"]))
+    assert np.median(np.abs(losses - d["losses"]) / d["losses"]) <= 2e-2
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_long_horizon_small_residual(golden, fmt):
+    """the lossy scratch formats at a horizon far beyond the 200-step plateau fixtures.  SIREN 256x8 on
+    the 128 x 128 non-smooth image, 2000 steps, StepLR(400, 0.5): the reference ends at 52.80 dB (8 threads) / 52.70 dB (2
+    threads) - its own spread is 0.0995 dB here, so the bound against it is spread + 0.05 dB; the three formats must agree
+    with EACH OTHER to 0.05 dB, which is the statement about the phase bytes and the fp8 deltas at small residuals
+    (see test_scratch_formats_agree_at_long_horizon)."""
+    d = golden("horizon_256x8_128")
+    lr_step = int(d["lr_step"])
+    psnr, losses = _fit(d, fmt, so.nonsmooth_image(128, 128), lambda t: 3e-4 * 0.5 ** (t // lr_step))
+    assert abs(psnr - float(d["psnr"])) <= float(d["psnr_spread"]) + 0.05, (psnr, float(d["psnr"]), float(d["psnr_2threads"]))
+    assert np.max(np.abs(losses[:4] - d["losses"][:4]) / d["losses"][:4]) <= 3e-3
+
+
+def test_scratch_formats_agree_at_long_horizon(golden):
+    d = golden("horizon_256x8_128")
+    lr_step = int(d["lr_step"])
+    img = so.nonsmooth_image(128, 128)
+    ps = [_fit(d, fmt, img, lambda t: 3e-4 * 0.5 ** (t // lr_step))[0] for fmt in FORMATS]
+    assert max(ps) - min(ps) <= float(d["psnr_spread"]) + 0.05, ps      # (the reference's own runs differ by 0.0995 dB)
+
+
+def test_fp8_chunk_scale_survives_a_100x_outlier():
+    """one pixel chunk whose residual has outliers 100x its bulk.  The chunk's power-of-two delta
+    scale is derived from the rms of dL/dout (k_bwd8<LAST>), so outliers sit far above it: they must saturate at +-448
+    (MODE.FP16_OVFL in k_bwd8h, v_med3 in k_bwd8), never turn into NaN, stay few, and leave the gradient inside the bound
+    of the numerics model - which here is dominated by the saturated outliers themselves, so the reference is the SAME
+    engine with 16-bit deltas (format 12: no saturation, same phase bytes)."""
+    H = W = 96
+    hidden, depth = 256, 5
+    p = so.siren_init(hidden, depth, seed=0)
+    g = torch.Generator().manual_seed(5)
+    pred = so.forward(p, so.get_grid(H, W))
+    img = (pred + 2e-3 * torch.randn(H, W, 3, generator=g)).clone()
+    out = torch.rand(H, W, generator=g) < 2e-3                     # ~18 outlier pixels, residual 100x the bulk
+    img[out] = img[out] + 0.2 * torch.sign(torch.randn(int(out.sum()), 3, generator=g))
+    img = img.float().contiguous()
+    grads = {}
+    for fmt in (12, 8):
+        eng = _engine(H, W, hidden, depth, "f16", p, img, scratch_format=fmt)
+        eng.forward_backward()
+        gr = eng.get_grads().cpu().numpy()
+        assert np.all(np.isfinite(gr)), fmt
+        grads[fmt] = gr
+        if fmt == 8:
+            deltas = eng.debug_scratch("deltas").cpu().numpy().view(np.uint8)
+            n_layers = depth - 1
+            per_layer = deltas.size // n_layers
+            used = H * W * hidden                                   # bytes of one layer's deltas that belong to pixels
+            for l in range(n_layers):
+                b = deltas[l * per_layer:l * per_layer + used]
+                assert not np.any((b & 0x7f) == 0x7f), l            # e4m3 NaN
+                sat = np.count_nonzero((b & 0x7f) == 0x7e)          # +-448
+                assert sat <= 0.02 * used, (l, sat, used)           # saturation stays a rare event
+    rel = np.linalg.norm(grads[8] - grads[12]) / np.linalg.norm(grads[12])
+    assert rel <= 0.1, rel
+
+
+# ---- BASELINE config 5: the sparse (RigL-masked) wide path --------------------------------------------------------------
+
+def test_erk_at_1024x12_reproduces_the_survey_counts():
+    """SURVEY 8a-M1 [probe]: ERK at 1024x12, density 0.1 -> hidden layers' probability 0.09956, 1 049 269 non-zeros of
+    10 490 880 weights (reference: core.py:386-423, init_scheme.py:40-158).  Runs the host mirror on the CPU RNG exactly as
+    the reference does (model init -> rand(1,1,2) -> masks), then pushes the masks to a 1024-wide ENGINE and checks that
+    what the engine holds is what was drawn."""
+    from implicit_image.models import Siren
+    from implicit_image.utils.train_helper import get_optimizer_lr_scheduler, setup_mask
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+    torch.manual_seed(0)
+    m = Siren(depth=12, hidden_size=1024, first_omega_0=50., hidden_omega_0=30.)
+    optim, _ = get_optimizer_lr_scheduler(m, Cfg(name="adam", lr=3e-4))
+    mcfg = Cfg(name="RigL", density=0.1, sparse_init="erdos-renyi-kernel", dense_gradients=True,
+               growth_mode="absolute-gradient", prune_mode="magnitude", redistribution_mode="none",
+               dense=False, prune_rate=0.1, decay_schedule="cosine", end_when=90, interval=20)
+    mask = setup_mask(m, optim, mcfg)
+    nnz = sum(int(v.sum().item()) for v in mask.mask_dict.values())
+    total = sum(v.numel() for v in mask.mask_dict.values())
+    assert (nnz, total) == (1049269, 10490880)
+    names = list(mask.mask_dict.keys())
+    hid = mask.mask_dict[names[1]]
+    assert abs(float(hid.mean()) - 0.09956) < 2e-3
+
+
+@pytest.mark.parametrize("hidden,depth,H,W", [(512, 4, 24, 40), (1024, 3, 16, 33)])
+def test_masks_on_the_wide_kernels(hidden, depth, H, W):
+    """masks set on a 512- and a 1024-wide engine stay exactly zero through 10 steps, and the losses
+    track the masked fp32 oracle (as test_masks_are_applied_inside_the_step does at width 64).  Reference:
+    masking/core.py:271-279 (apply_mask), 671-702 (step)."""
+    p = so.siren_init(hidden, depth, seed=0)
+    img = so.synthetic_image(H, W, seed=9)
+    eng = _engine(H, W, hidden, depth, "f16", p, img)
+    gen = torch.Generator().manual_seed(1)
+    masks, flat = [], []
+    for q in p:
+        mk = (torch.rand(q.shape, generator=gen) < 0.1).float() if (q.dim() == 2 and min(q.shape) == hidden) else torch.ones_like(q)
+        masks.append(mk if q.dim() == 2 else None)
+        flat.append(mk.reshape(-1))
+        q.mul_(mk)
+    eng.set_params(torch.tensor(so.flatten(p)).cuda())
+    eng.set_masks(torch.cat(flat).cuda())
+    opt = so.Adam(p)
+    grid = so.get_grid(H, W)
+    ref = [so.train_epoch(p, opt, grid, img, t, masks=masks) for t in range(10)]
+    got = eng.step([3e-4] * 10, want_loss=True)
+    assert np.max(np.abs(np.array(got) - np.array(ref)) / np.array(ref)) <= 3e-3, (got, ref)
+    w = eng.get_params().cpu()
+    assert torch.all(w[torch.cat(flat) == 0] == 0)               # bit-exact: masked weights stay zero
+    assert _rel_t(w, torch.tensor(so.flatten(p))) <= 2e-3
+
+
+def _rel_t(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def test_config5_sparse_rank_shard_of_the_8192_grid():
+    """BASELINE config 5 as one of its eight ranks sees it, SPARSE: SIREN 1024x12 with 10 %-dense masks on the hidden
+    layers, rows [0, 1024) of the 8192 x 8192 grid (eight 1 Mi-pixel chunks).  Properties that do not need the reference
+    at this size: a second pass is bit-identical, masked weights are exactly zero after two steps, and the two 512-row
+    halves add up to the shard's SSE and gradient (fp32 summation-order bound)."""
+    H = W = 8192
+    R = 1024
+    hidden, depth = 1024, 12
+    p = so.siren_init(hidden, depth, seed=0)
+    gen = torch.Generator().manual_seed(3)
+    flat = []
+    for q in p:
+        mk = (torch.rand(q.shape, generator=gen) < 0.1).float() if (q.dim() == 2 and min(q.shape) == hidden) else torch.ones_like(q)
+        flat.append(mk.reshape(-1))
+        q.mul_(mk)
+    mflat = torch.cat(flat).cuda()
+    ys = torch.linspace(0, 1, H, device="cuda")[:R, None, None]
+    xs = torch.linspace(0, 1, W, device="cuda")[None, :, None]
+    k = torch.tensor([1.0, 2.0, 3.0], device="cuda")
+    img = (0.5 + 0.25 * torch.sin(12 * xs * k) + 0.25 * torch.cos(9 * ys * k)).contiguous()
+    full = _engine(H, W, hidden, depth, "f16", p, row_begin=0, row_end=R)
+    full.set_masks(mflat)
+    full.set_target(img)
+    sse = full.forward_backward()
+    g = full.get_grads().clone()
+    assert math.isfinite(sse) and torch.isfinite(g).all() and g.abs().max().item() > 0
+    assert full.forward_backward() == sse and torch.equal(full.get_grads(), g)
+    full.step([3e-4] * 2)
+    assert torch.all(full.get_params()[mflat == 0] == 0)
+    full.close()
+    tot, gs = 0.0, torch.zeros_like(g)
+    for r0, r1 in ((0, 512), (512, 1024)):
+        part = _engine(H, W, hidden, depth, "f16", p, row_begin=r0, row_end=r1)
+        part.set_masks(mflat)
+        part.set_target(img[r0:r1].contiguous())
+        tot += part.forward_backward()
+        gs += part.get_grads()
+        part.close()
+    assert abs(tot - sse) <= 1e-6 * sse
+    assert (gs - g).norm().item() <= 1e-5 * g.norm().item()
