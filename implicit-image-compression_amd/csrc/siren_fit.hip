@@ -9,6 +9,7 @@
 #include "siren_s8.hip"
 #include "siren_s8h.hip"
 #include "siren_wide.hip"
+#include "siren_kmeans.hip"
 
 #include <math.h>
 #include <stdio.h>
@@ -107,6 +108,7 @@ struct sf_engine {
   bool d8 = false;        // fp8 deltas under a per-chunk adaptive pre-scale (scratch_format 8)
   bool fmt_auto = false;  // scratch_format was 0 at sf_create: the engine picks it, and moves to 16 when a mask is set
   long d_stride = 0;      // pieces per layer in the delta scratch (p_stride: phases)
+  KmWs* km_ws = nullptr;        // sf_kmeans_fit workspace (allocated on first use)
   char* pad8 = nullptr;         // k_bwd8h: 1 KiB of zeros, then (at +8 KiB) an 8 KiB dump
   float* scale_dev = nullptr;   // {gpre / n_values_total, 1 / gpre} as the kernels read them (adaptive when s8)
   // data
@@ -1083,7 +1085,7 @@ int sf_destroy(sf_handle* h) try {
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab, h->l0img,
                   h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part, h->biasw, h->Abuf,
-                  h->sse_dev, h->scale_dev, h->pad8};
+                  h->sse_dev, h->scale_dev, h->pad8, h->km_ws};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->gexec) hipGraphExecDestroy(h->gexec);
   if (h->gstream) { hipStreamSynchronize(h->gstream); hipStreamDestroy(h->gstream); hipEventDestroy(h->gev_in); hipEventDestroy(h->gev_out); }
@@ -1460,6 +1462,35 @@ int sf_profile_get(sf_handle* h, int32_t idx, const char** name, double* total_m
   const double nl = h->prof_n[idx] > 0 ? (double)h->prof_n[idx] : 1.0;
   if (flops_per_launch) *flops_per_launch = h->prof_flops[idx] / nl;
   if (bytes_per_launch) *bytes_per_launch = h->prof_bytes[idx] / nl;
+  return SF_OK;
+} SF_CATCH
+
+/* k-means weight quantisation of one tensor on the handle's stream, no host synchronisation (siren_kmeans.hip) */
+int sf_kmeans_fit(sf_handle* h, const float* w_dev, int64_t n, float* centers_dev, int32_t K, int32_t iter_limit, float tol,
+                  float* centroids_dev, int32_t centroids_cap, int32_t* n_centroids_dev, int64_t* labels_dev,
+                  float* new_weight_dev) try {
+  if (!h || !w_dev || !centers_dev || !centroids_dev) return fail(SF_ERR_INVALID, "null argument");
+  if (n <= 0 || K < 1 || K >= kKmMaxK || centroids_cap < K + 1 || iter_limit < 0)
+    return fail(SF_ERR_INVALID, "sf_kmeans_fit: need n > 0, 1 <= K < 512, centroids_cap >= K + 1");
+  DevGuard dev_guard(h->cfg.device);
+  if (!h->km_ws) {
+    if (hipMalloc((void**)&h->km_ws, sizeof(KmWs)) != hipSuccess) return fail(SF_ERR_NOMEM, "hipMalloc failed (k-means workspace)");
+    HIPCHK(hipMemsetAsync(h->km_ws, 0, sizeof(KmWs), h->stream));
+  }
+  long blocks = (n + 255) / 256;
+  const long cap = 4L * h->dw_wg;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_km_init, dim3(1), dim3(kKmMaxK), 0, h->stream, (const float*)centers_dev, (int)K, (long)n, h->km_ws);
+  for (int it = 0; it < iter_limit; ++it) {
+    hipLaunchKernelGGL(k_km_assign, dim3((unsigned)blocks), dim3(256), 0, h->stream, w_dev, (long)n, (const float*)centers_dev, (int)K, h->km_ws);
+    hipLaunchKernelGGL(k_km_update, dim3(1), dim3(kKmMaxK), 0, h->stream, centers_dev, (int)K, h->km_ws, tol);
+  }
+  hipLaunchKernelGGL(k_km_finish, dim3(1), dim3(kKmMaxK), 0, h->stream, (const float*)centers_dev, (int)K, h->km_ws, centroids_dev,
+                     (int)centroids_cap, n_centroids_dev);
+  if (labels_dev || new_weight_dev)
+    hipLaunchKernelGGL(k_km_predict, dim3((unsigned)blocks), dim3(256), 0, h->stream, w_dev, (long)n, (const float*)centroids_dev,
+                       (const KmWs*)h->km_ws, (long long*)labels_dev, new_weight_dev);
+  HIPCHK(hipGetLastError());
   return SF_OK;
 } SF_CATCH
 

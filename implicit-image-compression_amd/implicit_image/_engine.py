@@ -59,6 +59,7 @@ def load_library():
         "sf_sse_ptr": [H, C.POINTER(C.c_void_p)],
         "sf_debug_scratch": [H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(I64)],
         "sf_debug_throw": [C.c_int32],
+        "sf_kmeans_fit": [H, F, I64, F, C.c_int32, C.c_int32, C.c_float, F, C.c_int32, C.c_void_p, C.c_void_p, F],
         "sf_params_changed": [H],
         "sf_set_coords": [H, F, F], "sf_set_target": [H, F],
         "sf_forward": [H, F, C.POINTER(C.c_double)],
@@ -189,6 +190,20 @@ class SirenEngine:
         p, n = C.c_void_p(), C.c_int64()
         _check(self.lib.sf_debug_scratch(self.h, {"phases": 0, "deltas": 1, "dlast": 2, "slabs": 3}[which], C.byref(p), C.byref(n)))
         return torch.as_tensor(_DevView(p.value, n.value, "|u1"), device=self.device)
+
+    def kmeans_fit(self, weight: torch.Tensor, guess: torch.Tensor, iter_limit: int = 5, tol: float = 1e-4):
+        """sf_kmeans_fit on this handle's stream, no host sync: (centroids [K+1, zero padded], n_centroids [device int32],
+        labels [int64, weight's shape], new_weight)."""
+        w = _f32_cuda(weight.reshape(-1))
+        centers = _f32_cuda(guess.reshape(-1)).clone()
+        K = centers.numel()
+        cent = torch.empty(K + 1, device=self.device)
+        ncent = torch.empty(1, dtype=torch.int32, device=self.device)
+        labels = torch.empty(w.numel(), dtype=torch.int64, device=self.device)
+        new_w = torch.empty_like(w)
+        _check(self.lib.sf_kmeans_fit(self.h, w.data_ptr(), w.numel(), centers.data_ptr(), K, iter_limit, tol, cent.data_ptr(), K + 1,
+                                      ncent.data_ptr(), labels.data_ptr(), new_w.data_ptr()))
+        return cent, ncent, labels.reshape(weight.shape), new_w.reshape(weight.shape)
 
     def params_changed(self):
         _check(self.lib.sf_params_changed(self.h))

@@ -1,5 +1,5 @@
 """K-means weight quantisation ("next" row §8f-1; reference: implicit_image/pipeline/quant/)."""
-from .kmeans import KmeansQuant, find_centroids, kmeans_fit, kmeans_predict, scatter_mean
+from .kmeans import KmeansQuant, find_centroids, find_centroids_native, kmeans_fit, kmeans_predict, scatter_mean
 from .context import Quantize
 
-__all__ = ["KmeansQuant", "Quantize", "find_centroids", "kmeans_fit", "kmeans_predict", "scatter_mean"]
+__all__ = ["KmeansQuant", "Quantize", "find_centroids", "find_centroids_native", "kmeans_fit", "kmeans_predict", "scatter_mean"]

@@ -51,6 +51,19 @@ def kmeans_predict(x: torch.Tensor, cluster_centers: torch.Tensor) -> torch.Tens
     return torch.argmin(_sq_dist(x, cluster_centers), dim=1)        # first index wins ties
 
 
+def find_centroids_native(weight: torch.Tensor, n_clusters: int, eng):
+    """The same on the engine's stream WITHOUT a host synchronisation (sf_kmeans_fit, csrc/siren_kmeans.hip): returns
+    (centroids zero-padded to n_clusters entries, n_centroids as a device int32, labels, new_weight).  The initial guess is
+    torch.linspace over masked min / max, so it is bit-identical to the torch path's."""
+    w = weight.detach().float().contiguous()
+    nz = w != 0
+    inf = torch.tensor(float("inf"), device=w.device)
+    mn = torch.where(nz, w, inf).min()
+    mx = torch.where(nz, w, -inf).max()
+    guess = torch.linspace(mn, mx, n_clusters - 1, device=w.device, dtype=w.dtype)
+    return eng.kmeans_fit(w, guess)
+
+
 def find_centroids(weight: torch.Tensor, n_clusters: int):
     """(centroids, labels, new_weight) of one weight tensor (kmeans.py:110-150): linspace(min,max)
     guess over the NON-ZERO weights with n_clusters-1 centres, 0 prepended, torch.unique, sorted by
@@ -89,8 +102,15 @@ class KmeansQuant:
     @torch.no_grad()
     def kmeans_modify_weights(self):
         """forward-pre-hook of the reference, for every quantised layer in module order (kmeans.py:66-72)."""
+        eng = getattr(self.model, "_engine", None)
         for m in self._targets:
-            centroids, labels, new_weight = find_centroids(m.weight.data, self.n_clusters)
+            if eng is not None and m.weight.is_cuda and self.n_clusters <= 512:
+                # native path: five small kernels per layer on the engine's stream, no host sync; the centroid tensor keeps
+                # its full 2^bits length (zero padded) until update_weights() trims it to the count the device reports
+                centroids, m.n_centroids, labels, new_weight = find_centroids_native(m.weight.data, self.n_clusters, eng)
+            else:
+                centroids, labels, new_weight = find_centroids(m.weight.data, self.n_clusters)
+                m.n_centroids = None
             m.labeled_weight, m.centroids = labels, centroids
             m.weight.data.copy_(new_weight)
 
@@ -114,6 +134,9 @@ class KmeansQuant:
         self.remove_hooks()
         for m in self._targets:
             centroids, labels = m.centroids, m.labeled_weight
+            if getattr(m, "n_centroids", None) is not None:
+                centroids = centroids[:int(m.n_centroids.item())]     # (the one host read of the quantise phase: at its end)
+                m.n_centroids = None
             m.centroids = nn.Parameter(centroids, requires_grad=False)
             m.labeled_weight = nn.Parameter(labels, requires_grad=False)
             m.weight.data.copy_(centroids[labels])

@@ -111,6 +111,18 @@ int sf_sse_ptr(sf_handle* h, double** dev_ptr);
 /* test / debugging aid: device address and size in bytes of an engine scratch tensor of the last pass.
  * which: 0 phases (all layers, layer stride = bytes / (depth-1)), 1 deltas, 2 dL/dout, 3 per-workgroup slabs */
 int sf_debug_scratch(sf_handle* h, int32_t which, void** dev_ptr, int64_t* bytes);
+/* 1-D k-means quantisation of one weight tensor on the handle's stream, NO host synchronisation.  Replaces
+ * pipeline/quant/kmeans.py:110-150 (find_centroids) + kmeans_helper.py:59-115 (kmeans_fit / kmeans_predict).
+ *   w_dev [n]            the weights (device); zeros are excluded from the fit, included in the prediction
+ *   centers_dev [K]      in: the initial guess - torch.linspace(min, max, K) over the non-zero weights, K = 2^bits - 1
+ *                        (kmeans.py:125-131); out: the Lloyd centres after <= iter_limit iterations (tol on (sum |dc|)^2)
+ *   centroids_dev [cap]  out: {0} U centres -> unique -> ordered by |c|, zero padded (cap >= K + 1)
+ *   n_centroids_dev      out (device int, may be NULL): how many of them are real
+ *   labels_dev [n]       out (may be NULL): argmin of the squared distance, first index wins (int64, as torch.argmin)
+ *   new_weight_dev [n]   out (may be NULL): centroids[labels] */
+int sf_kmeans_fit(sf_handle* h, const float* w_dev, int64_t n, float* centers_dev, int32_t K, int32_t iter_limit, float tol,
+                  float* centroids_dev, int32_t centroids_cap, int32_t* n_centroids_dev, int64_t* labels_dev,
+                  float* new_weight_dev);
 /* test aid for the "never throws" promise above: raises inside the library on purpose (0: std::bad_alloc -> SF_ERR_NOMEM,
  * 1: std::runtime_error, 2: a non-std exception -> SF_ERR_INVALID); every entry point is a function-try-block */
 int sf_debug_throw(int32_t kind);

@@ -88,6 +88,26 @@ def main():
         for h in [*comp.forward_pre_hook_ll, *comp.backward_hook_ll]:
             h.remove()
     np.savez_compressed(f"{OUT}/kmeans_64x64.npz", **out)
+
+    # ---- round 3: a 256 x 256 layer (the metric model's hidden size), 30 % of it pruned, bits 5 (the reference's default,
+    # conf/quant/kmeans.yaml) and 8 ---------------------------------------------------------------------------------------
+    torch.manual_seed(0)
+    big = siren.Siren(depth=4, hidden_size=256, first_omega_0=50, hidden_omega_0=30)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(12)
+        big.layers[1].linear.weight.mul_((torch.rand(256, 256, generator=g) > 0.3).float())
+    out2 = {"weight": big.layers[1].linear.weight.data.clone().numpy()}
+    for bits in (5, 8):
+        comp = KmeansQuant(big, torch.optim.Adam(big.parameters(), lr=3e-4), bits=bits, skip_ll=["layers.0.linear", "layers.3.linear"])
+        cent, labels, new_w = comp.find_centroids(big.layers[1].linear)
+        out2[f"b{bits}_centroids"] = cent.numpy()
+        out2[f"b{bits}_labels"] = labels.numpy().astype(np.int16)
+        for h in [*comp.forward_pre_hook_ll, *comp.backward_hook_ll]:
+            h.remove()
+    np.savez_compressed(f"{OUT}/kmeans_256x256.npz", **out2)
+    print("kmeans 256x256: centroids", {k: v.shape for k, v in out2.items() if "centroids" in k})
+    if os.environ.get("KMEANS_ONLY"):
+        return
     print("kmeans: centroids", {k: v.shape for k, v in out.items() if "centroids" in k})
 
     # ---- container: quantise (8 bit), convert, half(), compress with plain and lzma --------------

@@ -133,6 +133,52 @@ def test_find_centroids_on_device_tensors(golden, bits, layer):
     assert np.allclose(new_w.cpu().numpy(), d[f"b{bits}_l{layer}_new_weight"], rtol=2e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("layer", [1, 2])
+def test_native_kmeans_labels_bit_exact(golden, bits, layer):
+    """sf_kmeans_fit (csrc/siren_kmeans.hip): the index path of kmeans.py:110-150 on the engine's
+    stream, no host synchronisation.  Labels and the centroid COUNT equal the reference's golden vectors bit for bit;
+    centroid values are exact segment means (64-bit fixed-point sums), the reference's are sequential float sums through
+    the absent torch_scatter: equal to ~1e-6 relative, "parity unpinned" at that boundary."""
+    from implicit_image._engine import SirenEngine
+    from implicit_image.pipeline.quant import find_centroids_native
+    d = golden("kmeans_64x64")
+    eng = SirenEngine(8, 8, 64, 4)
+    w = torch.tensor(d[f"b{bits}_l{layer}_weight"]).cuda()
+    cent, ncent, labels, new_w = find_centroids_native(w, 2 ** bits, eng)
+    ref_c = d[f"b{bits}_l{layer}_centroids"]
+    assert int(ncent.item()) == ref_c.size and cent.numel() == 2 ** bits
+    assert np.array_equal(labels.cpu().numpy(), d[f"b{bits}_l{layer}_labels"])
+    assert np.allclose(cent.cpu().numpy()[:ref_c.size], ref_c, rtol=2e-6, atol=1e-9) and torch.all(cent[ref_c.size:] == 0)
+    assert np.allclose(new_w.cpu().numpy(), d[f"b{bits}_l{layer}_new_weight"], rtol=2e-6, atol=1e-9)
+    c2, n2, l2, _ = find_centroids_native(w, 2 ** bits, eng)                      # deterministic: integer segment sums
+    assert torch.equal(c2, cent) and torch.equal(l2, labels) and int(n2.item()) == int(ncent.item())
+    eng.close()
+
+
+@pytest.mark.parametrize("bits", [5, 8])
+def test_native_kmeans_at_the_metric_width(golden, bits):
+    """The same at 256 x 256 with 30 % of the layer pruned (tests/golden/kmeans_256x256.npz, the reference's own code at
+    bits 5 - its default, conf/quant/kmeans.yaml - and 8): labels bit-exact, and equal to the torch host mirror's."""
+    from implicit_image._engine import SirenEngine
+    from implicit_image.pipeline.quant import find_centroids, find_centroids_native
+    d = golden("kmeans_256x256")
+    eng = SirenEngine(8, 8, 256, 4)
+    w = torch.tensor(d["weight"]).cuda()
+    cent, ncent, labels, new_w = find_centroids_native(w, 2 ** bits, eng)
+    n = int(ncent.item())
+    assert n == d[f"b{bits}_centroids"].size
+    assert np.array_equal(labels.cpu().numpy(), d[f"b{bits}_labels"])
+    assert np.allclose(cent.cpu().numpy()[:n], d[f"b{bits}_centroids"], rtol=2e-6, atol=1e-9)
+    assert torch.all(new_w[w == 0] == 0)                                           # label 0 = the pruned set
+    # the torch host mirror on the same device tensor sums with float atomics: its centroids differ in the last bits and,
+    # at bits = 5 (wide clusters), a few labels next to a boundary with them - the native path is the one that reproduces
+    # the reference's labels
+    ct, lt, _ = find_centroids(w, 2 ** bits)
+    assert float((lt != labels).float().mean()) <= 2e-3 and torch.allclose(ct, cent[:n], rtol=1e-5, atol=1e-8)
+    eng.close()
+
+
 def test_quant_phase_of_a_masked_fit_keeps_the_topology(tmp_path, monkeypatch):
     """RigL + k-means through the `make fit` entry: the quantised copy is fine-tuned with the final mask inside its
     engine, so the artefact that is saved is as sparse as the fit (label 0 = the pruned set), and its PSNR stays
