@@ -438,7 +438,7 @@ def test_make_fit_entry_runs_the_reference_loop(tmp_path, monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.chdir(tmp_path)
     cfg = load_config(os.path.join(root, "conf"), ["img.height=64", "img.width=64", "img.seed=3", "mlp.hidden_size=64",
-                                                   "mlp.depth=4", "train.num_steps=100", "train.log_steps=50"])
+                                                   "mlp.depth=4", "train.num_steps=100", "train.log_steps=50", "masking=none", "quant=none"])
     res = fit_one(cfg, torch.device("cuda", 0), str(tmp_path / "out"))
     p = so.siren_init(64, 4, seed=0)
     img, grid, opt = so.synthetic_image(64, 64, seed=3), so.get_grid(64, 64), so.Adam(p)
@@ -460,7 +460,7 @@ def test_make_fit_quant_and_compress_tail(tmp_path, monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.chdir(tmp_path)
     cfg = load_config(os.path.join(root, "conf"), ["img.height=64", "img.width=64", "mlp.hidden_size=64", "mlp.depth=4",
-                                                   "train.num_steps=300", "train.log_steps=300", "quant=kmeans",
+                                                   "train.num_steps=300", "train.log_steps=300", "masking=none", "quant=kmeans",
                                                    "quant.num_steps=10", "quant.log_steps=10"])
     res = fit_one(cfg, torch.device("cuda", 0), str(tmp_path / "out"))
     # the 10-step fine-tune re-clusters every forward and is chaotic (27..30 dB seen for a 32.6 dB model); the

@@ -19,7 +19,9 @@ def test_config_defaults_groups_overrides_interpolation():
     c = load_config(CONF, [])
     assert c.mlp.name == "siren" and c.mlp.hidden_size == 128 and c.mlp.depth == 8      # conf/mlp/siren.yaml
     assert c.optim.lr == pytest.approx(3e-4) and isinstance(c.optim.lr, float)
-    assert not c.masking and not c.quant                                                # dense fit
+    assert c.masking.name == "RigL" and c.quant.name == "KMeans" and c.entropy_coding.stream_name == "plain"   # the reference's default composition
+    d = load_config(CONF, ["masking=none", "quant=none"])
+    assert not d.masking and not d.quant                                                # dense fit
     assert c.exp_name == "siren_synthetic" and c.train.batch_height == c.img.height
     c = load_config(CONF, ["masking=RigL", "masking.density=0.1", "+mlp.hidden_size=256", "img=flower"], cwd="/x")
     assert c.masking.name == "RigL" and c.masking.density == 0.1 and c.masking.prune_rate == 0.1
