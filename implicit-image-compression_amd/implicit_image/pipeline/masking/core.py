@@ -84,26 +84,32 @@ class Masking:
         return st["momentum_buffer"]
 
     def calc_redistributed_densities(self):
-        """Per-layer regrowth counts proportional to the redistribution statistic, capped at 99 % of the free
-        slots with the overflow spread over the other layers (core.py:299-360)."""
-        residual, mean_residual, name2regrowth, i = 9999, 0, {}, 0
-        while residual > 0 and i < 1000:
-            residual = 0
-            for name in self.stats.variance_dict:
-                max_regrowth = self.stats.zeros_dict[name] + self.stats.removed_dict[name]
-                if name in name2regrowth:
-                    regrowth = name2regrowth[name]
-                else:
-                    regrowth = round(self.stats.variance_dict[name] * (self.stats.total_removed + self.adjusted_growth))
-                regrowth += mean_residual
-                if regrowth > 0.99 * max_regrowth:
-                    name2regrowth[name] = 0.99 * max_regrowth
-                    residual += regrowth - name2regrowth[name]
-                else:
-                    name2regrowth[name] = regrowth
-            mean_residual = residual / len(name2regrowth) if name2regrowth else 0
-            i += 1
-        return name2regrowth
+        """Regrowth budget per layer (reference behaviour: core.py:299-360): proportional to the redistribution statistic,
+        no layer above 99 % of its free slots, what a capped layer cannot take is shared out equally and the shares are
+        re-capped until nothing is left over (at most 1000 rounds).
+
+        Own form: a water-filling over arrays - every round adds the same share to all budgets, clips them at the caps and
+        collects the clipped excess (summed in layer order, as the reference accumulates it, so the float sequence and
+        therefore the rounded budgets equal tests/golden/masking_snfs.npz bit for bit)."""
+        names = list(self.stats.variance_dict)
+        if not names:
+            return {}
+        pool = self.stats.total_removed + self.adjusted_growth
+        caps = [0.99 * (self.stats.zeros_dict[n] + self.stats.removed_dict[n]) for n in names]
+        budget = [round(self.stats.variance_dict[n] * pool) for n in names]      # (ints until a share is added)
+        share = 0
+        for _ in range(1000):
+            excess = 0
+            for j, cap in enumerate(caps):
+                want = budget[j] + share
+                if want > cap:
+                    excess += want - cap
+                    want = cap
+                budget[j] = want
+            share = excess / len(names)
+            if not excess > 0:
+                break
+        return dict(zip(names, budget))
 
     # ---- setup (core.py:220-248, 386-423) ---------------------------------------------------
     def add_module(self, module: nn.Module):

@@ -100,39 +100,42 @@ def magnitude_prune(masking, mask: torch.Tensor, weight: torch.Tensor, name: str
 
 
 def global_magnitude_prune(masking) -> int:
-    """prune.py:54-104: one global |w| threshold, adapted multiplicatively until the number of removed
-    weights is within `tolerance` of ceil(prune_rate * baseline_nonzero) (or 10 stalled tries); masks are
-    then rewritten in place as |w| > threshold."""
-    tokill = math.ceil(masking.prune_rate * masking.baseline_nonzero)
-    if tokill <= 0:
+    """One global |w| threshold over all masked layers (reference behaviour: prune.py:54-104): the threshold kept on the
+    Masking object is nudged multiplicatively until the number of weights it removes is within `tolerance` of
+    ceil(prune_rate * baseline_nonzero), or the count has not moved for 10 tries; the masks then become |w| > threshold.
+
+    Own form: the magnitudes of every masked layer are sorted ONCE; "how many survive threshold t" is then a binary search
+    (N - searchsorted(t, right=True)) instead of a pass over every layer per trial - same integer counts, hence the same
+    threshold sequence and the same masks as the reference's per-layer sums (tests/golden/masking_pruning.npz)."""
+    target = math.ceil(masking.prune_rate * masking.baseline_nonzero)
+    if target <= 0:
         return 0
-    total_removed, prev_removed = 0, 0
-    increment, tries = masking.increment, 0
-    while abs(total_removed - tokill) > tokill * masking.tolerance:
-        total_removed = 0
-        for name, weight in masking.module.named_parameters():
-            if name not in masking.mask_dict:
-                continue
-            remain = (torch.abs(weight.data) > masking.prune_threshold).sum().item()
-            total_removed += masking.stats.nonzeros_dict[name] - remain
-        if prev_removed == total_removed:
-            tries += 1
-            if tries == 10:
-                break
-        else:
-            tries = 0
-        prev_removed = total_removed
-        if total_removed > tokill * (1.0 + masking.tolerance):
-            masking.prune_threshold *= 1.0 - increment
-            increment *= 0.99
-        elif total_removed < tokill * (1.0 - masking.tolerance):
-            masking.prune_threshold *= 1.0 + increment
-            increment *= 0.99
-    for name, weight in masking.module.named_parameters():
-        if name not in masking.mask_dict:
-            continue
-        masking.mask_dict[name][:] = (torch.abs(weight.data) > masking.prune_threshold)
-    return int(total_removed)
+    layers = [(n, w) for n, w in masking.module.named_parameters() if n in masking.mask_dict]
+    magnitudes = torch.sort(torch.cat([w.data.abs().reshape(-1) for _, w in layers])).values
+    alive = sum(masking.stats.nonzeros_dict[n] for n, _ in layers)
+
+    def removed_by(threshold: float) -> int:
+        t = torch.tensor(threshold, dtype=magnitudes.dtype, device=magnitudes.device)      # (the comparison is in the weights' dtype)
+        survivors = magnitudes.numel() - int(torch.searchsorted(magnitudes, t, right=True))
+        return alive - survivors
+
+    slack = target * masking.tolerance
+    step, removed, previous, stalled = masking.increment, 0, 0, 0
+    while abs(removed - target) > slack:
+        removed = removed_by(masking.prune_threshold)
+        stalled = stalled + 1 if removed == previous else 0
+        if stalled == 10:
+            break
+        previous = removed
+        if removed > target * (1.0 + masking.tolerance):        # too many gone: lower the bar
+            masking.prune_threshold *= 1.0 - step
+            step *= 0.99
+        elif removed < target * (1.0 - masking.tolerance):      # too few: raise it
+            masking.prune_threshold *= 1.0 + step
+            step *= 0.99
+    for name, weight in layers:
+        masking.mask_dict[name][:] = weight.data.abs() > masking.prune_threshold
+    return int(removed)
 
 
 prune_registry = {"magnitude": magnitude_prune, "global-magnitude": global_magnitude_prune}

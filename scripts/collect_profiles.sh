@@ -8,7 +8,7 @@ R=$PWD
 out=$R/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_stats_bench.json 2> $out/${tag}_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-formats > $out/${tag}_stats_bench.json 2> $out/${tag}_stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_FETCH_SIZE -- python3 $R/scripts/prof_step.py 2048 2 > /dev/null 2> $out/${tag}_pmc1.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_WRITE_SIZE -- python3 $R/scripts/prof_step.py 2048 2 > /dev/null 2> $out/${tag}_pmc2.err
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/${tag}_sq -- python3 $R/scripts/prof_step.py 2048 2 > /dev/null 2> $out/${tag}_pmc3.err
