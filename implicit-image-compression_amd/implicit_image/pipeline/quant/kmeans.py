@@ -102,7 +102,10 @@ class KmeansQuant:
     @torch.no_grad()
     def kmeans_modify_weights(self):
         """forward-pre-hook of the reference, for every quantised layer in module order (kmeans.py:66-72)."""
+        import os
         eng = getattr(self.model, "_engine", None)
+        if os.environ.get("SIREN_FIT_NATIVE_KMEANS", "1") == "0":       # A/B knob: the torch host mirror
+            eng = None
         for m in self._targets:
             if eng is not None and m.weight.is_cuda and self.n_clusters <= 512:
                 # native path: five small kernels per layer on the engine's stream, no host sync; the centroid tensor keeps
