@@ -8,6 +8,7 @@
 #include "siren_kernels.hip"
 #include "siren_s8.hip"
 #include "siren_s8h.hip"
+#include "siren_fwd16.hip"
 #include "siren_wide.hip"
 #include "siren_kmeans.hip"
 
@@ -99,6 +100,7 @@ struct sf_engine {
   uint16_t *wf = nullptr, *wf_last = nullptr, *wb = nullptr, *wb_last = nullptr;
   f32x4* l0tab = nullptr;
   uint16_t* l0img = nullptr;   // layer 0 as MFMA fragments (hidden 256: k_fwd_pipe)
+  uint16_t *wf16 = nullptr, *wf16_last = nullptr, *l0img16 = nullptr;   // images of the 16x16x32 forward (k_fwd_pipe16)
   float* biasw = nullptr;   // wide path: pre-scaled fp32 biases of layers 1..D-1
   bool wide = false;        // hidden > 256: layer-at-a-time kernels (siren_wide.hip)
   bool images_dirty = true;
@@ -243,7 +245,23 @@ int launch_fwd_pipe(sf_engine* h, const FwdArgs& a, int n_wg, bool train) {
     if (rc) return rc;                                                   \
     hipLaunchKernelGGL((k_fwd_pipe<OP, TR, S8>), dim3(n_wg), dim3(512), lds, h->stream, a); \
   } while (0)
-  if (f16 && train && h->s8) SF_FWDP(OpF16, true, true);
+  // The 16x16x32 re-tile of the pipeline (siren_fwd16.hip) is built, parity-tested and measured 3 % SLOWER than k_fwd_pipe on
+  // the same box (+9 % clock, +11 % cycles: DESIGN.md section 4c): it runs only when SIREN_FIT_FWD16=1 asks for it.
+  static const bool use16 = getenv("SIREN_FIT_FWD16") && atoi(getenv("SIREN_FIT_FWD16")) == 1;
+  if (f16 && h->wf16 && use16 && (!train || h->s8)) {   // phase-byte scratch or evaluation
+    FwdArgs b = a;
+    b.wf = reinterpret_cast<const u32x4*>(h->wf16); b.wf_last = reinterpret_cast<const u32x4*>(h->wf16_last);
+    b.l0img = reinterpret_cast<const u32x4*>(h->l0img16);
+    if (train) {
+      int rc = set_lds(k_fwd_pipe16<true>, lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_fwd_pipe16<true>), dim3(n_wg), dim3(512), lds, h->stream, b);
+    } else {
+      int rc = set_lds(k_fwd_pipe16<false>, lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_fwd_pipe16<false>), dim3(n_wg), dim3(512), lds, h->stream, b);
+    }
+  } else if (f16 && train && h->s8) SF_FWDP(OpF16, true, true);
   else if (f16 && train) SF_FWDP(OpF16, true, false);
   else if (f16) SF_FWDP(OpF16, false, false);
   else if (train) SF_FWDP(OpBF16, true, false);
@@ -468,6 +486,15 @@ int refresh_images(sf_engine* h) {
   if (n < 1024) n = 1024;
   Launch L(h, K_IMAGES, 0, (double)n * 8);
   hipLaunchKernelGGL(k_images, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+  if (h->wf16) {
+    Img16Args b;
+    memset(&b, 0, sizeof(b));
+    b.params = h->params; b.depth = h->D; b.out_features = h->cfg.out_features;
+    for (int l = 0; l < h->D; ++l) { b.off_w[l] = h->off_w[l]; b.off_b[l] = h->off_b[l]; }
+    b.wscale = a.wscale; b.hscale = a.hscale; b.sc_first = a.sc_first;
+    b.wf = h->wf16; b.wf_last = h->wf16_last; b.l0img = h->l0img16;
+    hipLaunchKernelGGL(k_images16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, b);
+  }
   L.done();
   HIPCHK(hipGetLastError());
   h->images_dirty = false;
@@ -1014,6 +1041,10 @@ int sf_create(const sf_config* cfg, sf_handle** out) try {
   }
   ALLOC(h->l0tab, (size_t)WD * 16);
   if (WD == 256) ALLOC(h->l0img, (size_t)(WD / 32) * 1024);
+  if (WD == 256 && D >= 3 && !h->wide && cfg->compute_dtype == SF_F16 && getenv("SIREN_FIT_FWD16") && atoi(getenv("SIREN_FIT_FWD16")) == 1) {
+    ALLOC(h->wf16, (size_t)(D - 2) * FwdGeom(WD).PIECES * 1024); ALLOC(h->wf16_last, (size_t)(WD / 16 + 1) * 1024);
+    ALLOC(h->l0img16, (size_t)(WD / 32) * 1024);
+  }
   ALLOC(h->gh, (size_t)cfg->height * 4); ALLOC(h->gw, (size_t)cfg->width * 4);
   ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->d_stride * 16);
   if (h->wide) ALLOC(h->Abuf, (size_t)(D - 1) * h->p_stride * 16);
@@ -1085,7 +1116,7 @@ int sf_destroy(sf_handle* h) try {
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {h->params, h->grads, h->m, h->v, h->mask, h->wf, h->wf_last, h->wb, h->wb_last, h->l0tab, h->l0img,
                   h->gh, h->gw, h->Pbuf, h->Dbuf, h->Dlast, h->slab, h->sse_part, h->biasw, h->Abuf,
-                  h->sse_dev, h->scale_dev, h->pad8, h->km_ws};
+                  h->sse_dev, h->scale_dev, h->pad8, h->km_ws, h->wf16, h->wf16_last, h->l0img16};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->gexec) hipGraphExecDestroy(h->gexec);
   if (h->gstream) { hipStreamSynchronize(h->gstream); hipStreamDestroy(h->gstream); hipEventDestroy(h->gev_in); hipEventDestroy(h->gev_out); }

@@ -1,0 +1,43 @@
+"""k_fwd_pipe16 (the 16x16x32 re-tile of the forward pipeline, csrc/siren_fwd16.hip; opt-in with SIREN_FIT_FWD16=1) against
+k_fwd_pipe (32x32x16, the default) on the same weights.  The two compute the same sums in a different MFMA order, so they
+agree to f32 rounding: predictions to 1e-4, phase bytes within one step of the byte in a small fraction of the places (the
+round-to-nearest boundary), identical layer-0 bytes (layer 0 has one k-step), gradients within the byte-flip noise.  The
+library reads the knob once per process, so each tiling runs in a child process of its own (one after the other)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp_path, knob, H, W, fmt):
+    out = tmp_path / f"t{knob}.npz"
+    child = os.path.join(ROOT, "tests", "_fwd_tiling_child.py")
+    r = subprocess.run([sys.executable, child, str(out), str(H), str(W), str(fmt)], env=dict(os.environ, SIREN_FIT_FWD16=str(knob)),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()
+    return np.load(out)
+
+
+@pytest.mark.parametrize("fmt", (8, 12))
+def test_forward_16x16x32_agrees_with_32x32x16(tmp_path, fmt):
+    H, W = 75, 53                                   # ragged: 3975 pixels = 15 full 256-pixel groups + 135
+    a, b = _run(tmp_path, 0, H, W, fmt), _run(tmp_path, 1, H, W, fmt)
+    assert np.abs(a["pred"] - b["pred"]).max() <= 1e-4
+    assert abs(float(a["sse"]) / float(b["sse"]) - 1) <= 1e-5 and abs(float(a["loss"]) / float(b["loss"]) - 1) <= 1e-5
+    pa, pb = a["phases"].view(np.uint8), b["phases"].view(np.uint8)
+    d = (pa.astype(np.int16) - pb.astype(np.int16) + 128) % 256 - 128
+    npl = pa.size // 7                               # seven planes: layers 0..6
+    valid = (H * W + 31) // 32 * 8 * 1024            # bytes of a plane that hold pixel blocks of this image
+    for l in range(7):
+        dl = d.reshape(-1)[l * npl:l * npl + valid]
+        assert np.abs(dl).max() <= 1, l
+        assert (dl != 0).mean() <= (0.0 if l == 0 else 5e-3), (l, (dl != 0).mean())
+    assert (d != 0).any()                            # (the other kernel did run)
+    assert np.abs(a["grads"] - b["grads"]).max() <= 1e-2 * np.abs(a["grads"]).max()
+    rel = np.abs(a["losses"] - b["losses"]) / a["losses"]
+    assert rel[:5].max() <= 2e-3     # (the fast descent then amplifies the byte flips: 3 % / 13 % apart after 20 steps, formats 8 / 12)
