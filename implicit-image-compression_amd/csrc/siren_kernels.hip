@@ -134,8 +134,10 @@ DEV float phase_rev8(uint32_t p) { return __builtin_fmaf((float)((p >> (8 * BYTE
 
 // Delta byte: OCP fp8 e4m3 (3-bit significand, 2^-9 .. 448), SATURATING (the plain conversion returns NaN beyond
 // +-448: isa_probe).  Deltas carry one power-of-two scale per pixel chunk, derived by k_bwd8<LAST> from the chunk's
-// own residual so that rms(dL/dout) lands in (4, 8]: e4m3's range then sits around the data at every stage of a fit,
+// own residual so that rms(residual * G) lands in (kFp8Target / 2, kFp8Target]: e4m3's range then sits around the data at
+// every stage of a fit (the hidden deltas are 0.1 - 5 x that, growing towards layer 0; 448 / 0.25 leaves the tails room),
 // and the consumer's fp8 -> fp16 conversion needs no scale at all (e4m3's range is inside fp16's).
+constexpr float kFp8Target = 0.5f;
 // (min/max with literals, not v_med3_f32: a VOP3 instruction cannot take a literal, and the two bounds would each
 //  occupy a register for the whole kernel)
 DEV float sat448(float x) { return __builtin_fmaxf(__builtin_fminf(x, 448.0f), -448.0f); }
@@ -1323,6 +1325,7 @@ struct ReduceArgs {
   int accumulate;                   // add to the existing gradient (later chunks)
   float scale;                      // 1 / gradient pre-scale (power of two; fp16 backward operands)
   const float* scale_dev;           // 8-bit scratch: scale_dev[1] = 1 / (chunk pre-scale * n_values) overrides `scale`
+  const float* scale2_dev;          // fp8 deltas: 1 / (cumulative per-layer delta scale of the layer's incoming deltas), or nullptr
 };
 
 // 256 threads = 16 outputs x 16 slab groups: group g sums slabs g, g+16, ... (independent loads, issued ahead),
@@ -1360,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     float t = sh[0][o];
 #pragma unroll
     for (int g = 1; g < 16; ++g) t += sh[g][o];
-    t *= a.scale_dev ? a.scale_dev[1] : a.scale;
+    t *= (a.scale_dev ? a.scale_dev[1] : a.scale) * (a.scale2_dev ? a.scale2_dev[0] : 1.0f);
     float* dst = idx < nW ? a.gW + idx : a.gb + (idx - nW);
     *dst = a.accumulate ? *dst + t : t;
   }
@@ -1370,8 +1373,9 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 // layout: out[i] = sum_w slab[w][i].  256 threads = 8 float4 columns x 32 slab groups; group g sums
 // slabs g, g+32, ... in order, groups are combined 0..31 in order (fixed order => deterministic).
 __global__ __launch_bounds__(256) void k_reduce_vec(const float* slab, int n_wg, long stride, int n4, float* out,
-                                                    int accumulate, float scale, const float* scale_dev) {
+                                                    int accumulate, float scale, const float* scale_dev, const float* scale2_dev) {
   if (scale_dev) scale = scale_dev[1];
+  if (scale2_dev) scale *= scale2_dev[0];      // (powers of two: exact)
   __shared__ f32x4 sh[32][8];
   const int col = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const int i4 = blockIdx.x * 8 + col;
@@ -1462,6 +1466,7 @@ struct ImgArgs {
   f32x4* l0tab;
   uint16_t* l0img;          // layer 0 as MFMA A fragments (k_fwd_pipe, see kL0Split), always fp16; nullptr: not built
   float sc_first;           // first_omega_0 / (2 pi)
+  const float* link;        // fp8 deltas: link[l] = power-of-two scale folded into the backward image of layer l (k_fp8_scales); nullptr: 1
 };
 DEV uint16_t to_bf16(float x) { return (uint16_t)(OpBF16::pack2(x, 0.f) & 0xffffu); }
 DEV uint16_t to_f16(float x) { return (uint16_t)(OpF16::pack2(x, 0.f) & 0xffffu); }
@@ -1476,6 +1481,61 @@ struct FwdGeom {
   __host__ __device__ int bias_piece(int nt) const { return nt < H0 ? H0 * KS : XP + H1 * KS; }
   __host__ __device__ int bias_off(int nt) const { return (nt < H0 ? nt : nt - H0) * 32; }
 };
+
+// ---------------------------------------------------------------------------------------------
+// k_fp8_scales: per-layer power-of-two scales of the fp8 deltas (scratch format 8), from the weights alone.
+// delta_{l-1} = (W_l^T delta_l) * omega_{l-1} cos(phi_{l-1}) has, for uncorrelated delta components,
+//   rms(delta_{l-1}) / rms(delta_l) = gain_l = omega_{l-1} * sqrt(0.5 * ||W_l||_F^2 / n_in)
+// (1.0 at the SIREN initialisation; measured on fits: the real growth is this times 1.0 - 1.6 per layer, 10 - 25 x from the
+// last hidden layer down to layer 0 where the prediction says 3 - 6 x: scripts/fp8_gain_probe.py).  One e4m3 scale per chunk
+// cannot hold seven tensors that far apart between the 448 saturation and the 2^-6 subnormals (the non-smooth 1000-step
+// fixture lost 1.6 dB to clipped layer-0 / layer-1 deltas), so every layer's outgoing deltas are divided by the predicted gain
+// rounded to a power of two: link[l] = 2^-round(log2(gain_l)) goes into the backward image of layer l (k_images) - no
+// instruction in any kernel - and the reduction of layer l's weight gradient multiplies by inv[l] = 1 / prod_{m > l} link[m].
+// The last layer's link also normalises its own gain, so rms(first hidden delta) ~ the chunk's target.
+// One workgroup; sums in double, fixed order: a function of the parameters only (no state, bit-reproducible).
+// ---------------------------------------------------------------------------------------------
+struct Fp8ScaleArgs {
+  const float* params;
+  int depth, WD, out_features;
+  long off_w[16];
+  float om_first, om_hidden;
+  float* link;     // [16]
+  float* inv;      // [16]
+};
+__global__ __launch_bounds__(256) void k_fp8_scales(Fp8ScaleArgs a) {
+  __shared__ double sh[256];
+  __shared__ double nrm[16];
+  const int t = threadIdx.x;
+  for (int l = 1; l < a.depth; ++l) {
+    const long n = (long)(l == a.depth - 1 ? a.out_features : a.WD) * a.WD;
+    const float* W = a.params + a.off_w[l];
+    double s = 0.0;
+    for (long i = t; i < n; i += 256) s += (double)W[i] * (double)W[i];
+    sh[t] = s;
+    __syncthreads();
+    if (t == 0) {
+      double tot = 0.0;
+      for (int i = 0; i < 256; ++i) tot += sh[i];
+      nrm[l] = tot;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double S = 1.0;                                  // cumulative scale of the deltas ENTERING layer l's weight gradient
+    for (int l = a.depth - 1; l >= 0; --l) {
+      a.inv[l] = (float)(1.0 / S);
+      if (l == 0) { a.link[0] = 1.0f; break; }
+      const double om = l - 1 == 0 ? (double)a.om_first : (double)a.om_hidden;
+      double gain = om * sqrt(0.5 * nrm[l] / (double)a.WD);
+      if (!(gain > 1e-6)) gain = 1e-6;               // (all-zero layer, NaN)
+      if (gain > 1e6) gain = 1e6;
+      const double lk = exp2(-floor(log2(gain) + 0.5));
+      a.link[l] = (float)lk;
+      S *= lk;
+    }
+  }
+}
 
 __global__ void k_images(ImgArgs a) {
   const int WD = a.WD, NT = WD / 32, KS = WD / 16;
@@ -1493,7 +1553,10 @@ __global__ void k_images(ImgArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const float* Wl = a.params + a.off_w[l];
     const float wfwd = Wl[(long)(32 * tile + r) * WD + 16 * s + pi_perm(h, j)] * a.hscale;
-    const float wbwd = Wl[(long)(16 * s + pi_perm(h, j)) * WD + 32 * tile + r] * (l - 1 == 0 ? a.om_first : a.om_hidden);
+    // (ONE factor: hipcc fuses W * factor and the conversion into v_fma_mixlo_f16, a single rounding; a second multiply would
+    //  round the product to f32 first and change one image element in some thousands - formats 16 / 12 must not move)
+    const float bsc = (l - 1 == 0 ? a.om_first : a.om_hidden) * (a.link ? a.link[l] : 1.0f);
+    const float wbwd = Wl[(long)(16 * s + pi_perm(h, j)) * WD + 32 * tile + r] * bsc;
     const long dst = ((long)(l - 1) * G.PIECES + G.tile_piece(tile) + s) * 512 + lane * 8 + j;
     a.wf[dst] = a.fwd_is_f16 ? to_f16(wfwd) : to_bf16(wfwd);
     a.wb[gid] = a.fwd_is_f16 ? to_f16(wbwd) : to_bf16(wbwd);
@@ -1527,7 +1590,7 @@ __global__ void k_images(ImgArgs a) {
     const int c = pi_perm(h, j);
     float w = 0.f;
     if (c < a.out_features)
-      w = a.params[a.off_w[L] + (long)c * WD + 32 * tile + r] * (L - 1 == 0 ? a.om_first : a.om_hidden);
+      w = a.params[a.off_w[L] + (long)c * WD + 32 * tile + r] * ((L - 1 == 0 ? a.om_first : a.om_hidden) * (a.link ? a.link[L] : 1.0f));
     a.wb_last[gid] = a.fwd_is_f16 ? to_f16(w) : to_bf16(w);
   }
   if (gid < WD) {

@@ -6,7 +6,7 @@
 //   phases  P_l   : u8 = round(t * 256) mod 256 (t in revolutions), written by k_fwd<.., S8>, one 1 KiB piece per
 //                   (32-pixel block, 32-neuron tile): byte 8q+j of lane (h,m) = neuron 32*tile + 16*q + PI(h,j)
 //   deltas  D_l   : OCP fp8 e4m3 in the same piece layout, in units of the step's power-of-two gradient pre-scale
-//                   (k_sse_reduce keeps rms(dL/dout) ~ 8, so e4m3's 2^-9 .. 448 sits around the data)
+//                   (k_bwd8<LAST> scales the chunk's residual rms to kFp8Target, so e4m3's 2^-9 .. 448 sits around the data)
 // => k_bwd8 moves 768 B per pixel (delta and phase in, delta out) where k_bwd moves 1 536: the round-1 kernel ran
 // at ~75 % of the box's achievable HBM rate, i.e. its time WAS its bytes.
 //

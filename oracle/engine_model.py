@@ -18,7 +18,7 @@ separate "rounding" (engine == this model to ~1e-5) from "algorithm" (this model
 
   scratch=8 (sf_config.scratch_format = 8; csrc/siren_s8.hip):
            phases spilled as bytes round(t*256) mod 256 and decoded as u/256 revolutions; dL/dout stored as
-           fp16(resid * 2^10); per pixel chunk G = 2^floor(log2(8 / rms(resid))); every hidden delta is
+           fp16(resid * 2^10); per pixel chunk G = 2^floor(log2(FP8_TARGET / rms(resid))), FP8_TARGET = 0.5 (csrc kFp8Target); every hidden delta is
            e4m3(saturate(.)) in units of G (the first one picks up G / 2^10 together with its cosine);
            gradients of the layers below the last are scaled by float(1 / (G * 3N)), the last layer's by
            float(1 / (2^10 * 3N)).
@@ -27,6 +27,8 @@ import math
 from typing import Sequence
 
 import torch
+
+FP8_TARGET = 0.5      # csrc/siren_kernels.hip kFp8Target
 
 TWO_PI = 2.0 * math.pi
 
@@ -107,6 +109,24 @@ def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torc
     return sse / (3.0 * n), sse, grads, pred.reshape(h, w, -1)
 
 
+def fp8_layer_scales(params, first_omega_0, hidden_omega_0):
+    """csrc k_fp8_scales: link[l] = 2^-round(log2(gain_l)), gain_l = omega_{l-1} sqrt(0.5 ||W_l||_F^2 / n_in) (sums in double);
+    inv[l] = 1 / prod_{m > l} link[m] multiplies the weight gradient of layer l."""
+    depth = len(params) // 2
+    link, inv = [1.0] * depth, [1.0] * depth
+    S = 1.0
+    for l in range(depth - 1, -1, -1):
+        inv[l] = 1.0 / S
+        if l == 0:
+            break
+        Wl = params[2 * l].double()
+        om = first_omega_0 if l - 1 == 0 else hidden_omega_0
+        gain = min(max(om * math.sqrt(0.5 * float((Wl * Wl).sum()) / Wl.shape[1]), 1e-6), 1e6)
+        link[l] = 2.0 ** -math.floor(math.log2(gain) + 0.5)
+        S *= link[l]
+    return link, inv
+
+
 def _loss_and_grads_s8(params, grid, img, first_omega_0, hidden_omega_0, n_total=None):
     """The 8-bit scratch path (fp16 operands): see the module docstring.  One pixel chunk (what every test uses)."""
     depth = len(params) // 2
@@ -134,12 +154,13 @@ def _loss_and_grads_s8(params, grid, img, first_omega_0, hidden_omega_0, n_total
     S0 = 1024.0
     dlast = _rt(resid * S0, "f16")
     rms = min(max(math.sqrt(sse / (img.shape[-1] * n)), 1e-12), 4.0)
-    G = 2.0 ** math.floor(math.log2(8.0 / rms))
+    G = 2.0 ** math.floor(math.log2(FP8_TARGET / rms))
     dfac = torch.tensor(G / S0, dtype=torch.float32)
     sc_hidden = torch.tensor(1.0 / (G * nv), dtype=torch.float32)
     sc_last = torch.tensor(1.0 / (S0 * nv), dtype=torch.float32)
     grads = [None] * (2 * depth)
     delta = dlast
+    link, inv = fp8_layer_scales(params, first_omega_0, hidden_omega_0)
     # round 3: at hidden 256 / depth >= 3 (k_fwd_pipe + k_bwd8h) layer 0's phases are spilled as bytes too and the backward
     # of layer 1 decodes them like any hidden layer's; elsewhere they are re-derived from the coordinates (fp32)
     l0_bytes = params[0].shape[0] == 256 and depth >= 3
@@ -149,17 +170,18 @@ def _loss_and_grads_s8(params, grid, img, first_omega_0, hidden_omega_0, n_total
         else:
             ph = q[l - 1] * (1.0 / 256.0) + PHASE_EPS
         act = _rt(torch.sin(TWO_PI * ph.double()).float(), "f16")
-        sc = sc_last if l == L else sc_hidden
+        sc = sc_last if l == L else sc_hidden * torch.tensor(inv[l], dtype=torch.float32)
         grads[2 * l] = (delta.t() @ act) * sc
         grads[2 * l + 1] = delta.sum(0) * sc
         om = first_omega_0 if l - 1 == 0 else hidden_omega_0
-        Gacc = delta @ _rt(params[2 * l] * om, "f16")
+        Gacc = delta @ _rt(params[2 * l] * torch.tensor(om * link[l], dtype=torch.float32), "f16")   # (link: a power of two in the image)
         c = torch.cos(TWO_PI * ph.double()).float()
         if l == L:
             c = c * dfac
         delta = _e4m3(Gacc * c)
     xh = _rt(x, "f16")
     xl = _rt(x - xh, "f16")
-    grads[0] = (delta.t() @ xh + delta.t() @ xl) * sc_hidden
-    grads[1] = delta.sum(0) * sc_hidden
+    sc0 = sc_hidden * torch.tensor(inv[0], dtype=torch.float32)
+    grads[0] = (delta.t() @ xh + delta.t() @ xl) * sc0
+    grads[1] = delta.sum(0) * sc0
     return sse / (img.shape[-1] * float(n)), sse, grads, pred.reshape(h, w, -1)

@@ -171,11 +171,14 @@ def test_native_kmeans_at_the_metric_width(golden, bits):
     assert np.array_equal(labels.cpu().numpy(), d[f"b{bits}_labels"])
     assert np.allclose(cent.cpu().numpy()[:n], d[f"b{bits}_centroids"], rtol=2e-6, atol=1e-9)
     assert torch.all(new_w[w == 0] == 0)                                           # label 0 = the pruned set
-    # the torch host mirror on the same device tensor sums with float atomics: its centroids differ in the last bits and,
-    # at bits = 5 (wide clusters), a few labels next to a boundary with them - the native path is the one that reproduces
-    # the reference's labels
-    ct, lt, _ = find_centroids(w, 2 ** bits)
-    assert float((lt != labels).float().mean()) <= 2e-3 and torch.allclose(ct, cent[:n], rtol=1e-5, atol=1e-8)
+    # ... and equal to the torch host mirror run on the CPU copy (deterministic sums).  On a CUDA tensor the mirror's
+    # index_add_ uses float atomics: its centroids move in the last bits from run to run and, at bits = 5 (wide clusters),
+    # a Lloyd iteration can tip - between 0.1 % and 5 % of its labels and single centroids then differ (seen on two boxes) -
+    # so that run is only checked to stay in the neighbourhood; the native path is the one that reproduces the reference's labels.
+    ct, lt, _ = find_centroids(w.cpu(), 2 ** bits)
+    assert torch.equal(lt, labels.cpu()) and torch.allclose(ct, cent[:n].cpu(), rtol=2e-6, atol=1e-9)
+    cg, _, _ = find_centroids(w, 2 ** bits)
+    assert cg.numel() == n and float((cg - cent[:n]).abs().max()) <= 0.1 * float(cent[:n].abs().max())   # (it runs; not pinned)
     eng.close()
 
 
