@@ -101,7 +101,7 @@ struct sf_engine {
   f32x4* l0tab = nullptr;
   uint16_t* l0img = nullptr;   // layer 0 as MFMA fragments (hidden 256: k_fwd_pipe)
   uint16_t *wf16 = nullptr, *wf16_last = nullptr, *l0img16 = nullptr;   // images of the 16x16x32 forward (k_fwd_pipe16)
-  float* lsc = nullptr;        // fp8 deltas: link[16] | inv[16] (k_fp8_scales), rebuilt with the weight images
+  float* lsc = nullptr;        // fp8 deltas: link[16] | inv[16] (k_fp8_norms + k_fp8_links), rebuilt with the weight images
   float* biasw = nullptr;   // wide path: pre-scaled fp32 biases of layers 1..D-1
   bool wide = false;        // hidden > 256: layer-at-a-time kernels (siren_wide.hip)
   bool images_dirty = true;
@@ -501,7 +501,9 @@ int refresh_images(sf_engine* h) {
     f.params = h->params; f.depth = h->D; f.WD = h->WD; f.out_features = h->cfg.out_features;
     for (int l = 0; l < h->D; ++l) f.off_w[l] = h->off_w[l];
     f.om_first = a.om_first; f.om_hidden = a.om_hidden; f.link = h->lsc; f.inv = h->lsc + 16;
-    hipLaunchKernelGGL(k_fp8_scales, dim3(1), dim3(256), 0, h->stream, f);
+    f.nrm = reinterpret_cast<double*>(h->lsc + 32);
+    hipLaunchKernelGGL(k_fp8_norms, dim3(h->D - 1), dim3(1024), 0, h->stream, f);
+    hipLaunchKernelGGL(k_fp8_links, dim3(1), dim3(64), 0, h->stream, f);
     a.link = h->lsc;
   }
   hipLaunchKernelGGL(k_images, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
@@ -1071,7 +1073,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) try {
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
   { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4 + 4096); }
   h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
-  ALLOC(h->sse_part, (h->n_sse + 64) * 4); ALLOC(h->sse_dev, 8); ALLOC(h->scale_dev, 16); ALLOC(h->pad8, 16384); ALLOC(h->lsc, 32 * 4);
+  ALLOC(h->sse_part, (h->n_sse + 64) * 4); ALLOC(h->sse_dev, 8); ALLOC(h->scale_dev, 16); ALLOC(h->pad8, 16384); ALLOC(h->lsc, 32 * 4 + 16 * 8);
   if (!rc && hipMemset(h->pad8, 0, 16384) != hipSuccess) rc = fail(SF_ERR_NOMEM, "hipMemset failed");
 #undef ALLOC
   if (rc) { sf_destroy(h); return rc; }

@@ -1466,7 +1466,7 @@ struct ImgArgs {
   f32x4* l0tab;
   uint16_t* l0img;          // layer 0 as MFMA A fragments (k_fwd_pipe, see kL0Split), always fp16; nullptr: not built
   float sc_first;           // first_omega_0 / (2 pi)
-  const float* link;        // fp8 deltas: link[l] = power-of-two scale folded into the backward image of layer l (k_fp8_scales); nullptr: 1
+  const float* link;        // fp8 deltas: link[l] = power-of-two scale folded into the backward image of layer l (k_fp8_links); nullptr: 1
 };
 DEV uint16_t to_bf16(float x) { return (uint16_t)(OpBF16::pack2(x, 0.f) & 0xffffu); }
 DEV uint16_t to_f16(float x) { return (uint16_t)(OpF16::pack2(x, 0.f) & 0xffffu); }
@@ -1483,7 +1483,7 @@ struct FwdGeom {
 };
 
 // ---------------------------------------------------------------------------------------------
-// k_fp8_scales: per-layer power-of-two scales of the fp8 deltas (scratch format 8), from the weights alone.
+// k_fp8_norms + k_fp8_links: per-layer power-of-two scales of the fp8 deltas (scratch format 8), from the weights alone.
 // delta_{l-1} = (W_l^T delta_l) * omega_{l-1} cos(phi_{l-1}) has, for uncorrelated delta components,
 //   rms(delta_{l-1}) / rms(delta_l) = gain_l = omega_{l-1} * sqrt(0.5 * ||W_l||_F^2 / n_in)
 // (1.0 at the SIREN initialisation; measured on fits: the real growth is this times 1.0 - 1.6 per layer, 10 - 25 x from the
@@ -1493,7 +1493,7 @@ struct FwdGeom {
 // rounded to a power of two: link[l] = 2^-round(log2(gain_l)) goes into the backward image of layer l (k_images) - no
 // instruction in any kernel - and the reduction of layer l's weight gradient multiplies by inv[l] = 1 / prod_{m > l} link[m].
 // The last layer's link also normalises its own gain, so rms(first hidden delta) ~ the chunk's target.
-// One workgroup; sums in double, fixed order: a function of the parameters only (no state, bit-reproducible).
+// Sums in double, fixed order: a function of the parameters only (no state, bit-reproducible).
 // ---------------------------------------------------------------------------------------------
 struct Fp8ScaleArgs {
   const float* params;
@@ -1502,38 +1502,42 @@ struct Fp8ScaleArgs {
   float om_first, om_hidden;
   float* link;     // [16]
   float* inv;      // [16]
+  double* nrm;     // [16] sums of squares of the layers' weights
 };
-__global__ __launch_bounds__(256) void k_fp8_scales(Fp8ScaleArgs a) {
-  __shared__ double sh[256];
-  __shared__ double nrm[16];
-  const int t = threadIdx.x;
-  for (int l = 1; l < a.depth; ++l) {
-    const long n = (long)(l == a.depth - 1 ? a.out_features : a.WD) * a.WD;
-    const float* W = a.params + a.off_w[l];
-    double s = 0.0;
-    for (long i = t; i < n; i += 256) s += (double)W[i] * (double)W[i];
-    sh[t] = s;
-    __syncthreads();
-    if (t == 0) {
-      double tot = 0.0;
-      for (int i = 0; i < 256; ++i) tot += sh[i];
-      nrm[l] = tot;
-    }
+// (two launches: the sums of squares one workgroup per layer - a single workgroup spent 120 us waiting on its own loads -
+//  then one thread for the seven links)
+__global__ __launch_bounds__(1024) void k_fp8_norms(Fp8ScaleArgs a) {
+  __shared__ double sh[1024];
+  const int t = threadIdx.x, l = 1 + (int)blockIdx.x;
+  const long n = (long)(l == a.depth - 1 ? a.out_features : a.WD) * a.WD;
+  const float* W = a.params + a.off_w[l];
+  double s = 0.0;
+#pragma unroll 8
+  for (long i = t; i < n; i += 1024) s += (double)W[i] * (double)W[i];
+  sh[t] = s;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {          // fixed tree: the same sum on every run
+    if (t < st) sh[t] += sh[t + st];
     __syncthreads();
   }
-  if (t == 0) {
-    double S = 1.0;                                  // cumulative scale of the deltas ENTERING layer l's weight gradient
-    for (int l = a.depth - 1; l >= 0; --l) {
-      a.inv[l] = (float)(1.0 / S);
-      if (l == 0) { a.link[0] = 1.0f; break; }
-      const double om = l - 1 == 0 ? (double)a.om_first : (double)a.om_hidden;
-      double gain = om * sqrt(0.5 * nrm[l] / (double)a.WD);
-      if (!(gain > 1e-6)) gain = 1e-6;               // (all-zero layer, NaN)
-      if (gain > 1e6) gain = 1e6;
-      const double lk = exp2(-floor(log2(gain) + 0.5));
-      a.link[l] = (float)lk;
-      S *= lk;
-    }
+  if (t == 0) a.nrm[l] = sh[0];
+}
+__global__ void k_fp8_links(Fp8ScaleArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double S = 1.0;                                  // cumulative scale of the deltas ENTERING layer l's weight gradient
+  for (int l = a.depth - 1; l >= 0; --l) {
+    a.inv[l] = (float)(1.0 / S);
+    if (l == 0) { a.link[0] = 1.0f; break; }
+    const double om = l - 1 == 0 ? (double)a.om_first : (double)a.om_hidden;
+    double gain = om * sqrt(0.5 * a.nrm[l] / (double)a.WD);
+    if (!(gain > 1e-6)) gain = 1e-6;               // (all-zero layer, NaN)
+    if (gain > 1e6) gain = 1e6;
+    int e = 0;
+    const double m = frexp(gain, &e);              // gain = m * 2^e, m in [0.5, 1): round(log2(gain)) = e - (m < sqrt(0.5))
+    const int k = e - (m < 0.70710678118654752440 ? 1 : 0);
+    const double lk = ldexp(1.0, -k);
+    a.link[l] = (float)lk;
+    S *= lk;
   }
 }
 

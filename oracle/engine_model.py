@@ -110,7 +110,7 @@ def loss_and_grads(params: Sequence[torch.Tensor], grid: torch.Tensor, img: torc
 
 
 def fp8_layer_scales(params, first_omega_0, hidden_omega_0):
-    """csrc k_fp8_scales: link[l] = 2^-round(log2(gain_l)), gain_l = omega_{l-1} sqrt(0.5 ||W_l||_F^2 / n_in) (sums in double);
+    """csrc k_fp8_norms + k_fp8_links: link[l] = 2^-round(log2(gain_l)), gain_l = omega_{l-1} sqrt(0.5 ||W_l||_F^2 / n_in) (sums in double);
     inv[l] = 1 / prod_{m > l} link[m] multiplies the weight gradient of layer l."""
     depth = len(params) // 2
     link, inv = [1.0] * depth, [1.0] * depth
@@ -122,7 +122,8 @@ def fp8_layer_scales(params, first_omega_0, hidden_omega_0):
         Wl = params[2 * l].double()
         om = first_omega_0 if l - 1 == 0 else hidden_omega_0
         gain = min(max(om * math.sqrt(0.5 * float((Wl * Wl).sum()) / Wl.shape[1]), 1e-6), 1e6)
-        link[l] = 2.0 ** -math.floor(math.log2(gain) + 0.5)
+        m, e = math.frexp(gain)                      # round(log2(gain)) as the kernel takes it: e - (m < sqrt(1/2))
+        link[l] = 2.0 ** -(e - (1 if m < 0.70710678118654752440 else 0))
         S *= link[l]
     return link, inv
 
