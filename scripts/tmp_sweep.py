@@ -1,0 +1,24 @@
+import os, sys, math
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "implicit-image-compression_amd"))
+from implicit_image._engine import SirenEngine
+from oracle import siren_oracle as so
+def fit(name, img, steps, lr_step, fmt=8):
+    d = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    H, W = int(d["height"]), int(d["width"])
+    p = so.siren_init(256, 8, seed=0)
+    eng = SirenEngine(H, W, 256, 8, compute_dtype="f16", scratch_format=fmt)
+    gh, gw = so.grid_vectors(H, W)
+    eng.set_coords(gh.cuda(), gw.cuda()); eng.set_params(torch.tensor(so.flatten(p)).cuda()); eng.set_target(img.cuda().contiguous())
+    losses = np.array(eng.step([3e-4 * 0.5 ** (t // lr_step) for t in range(steps)], want_loss=True))
+    _, sse = eng.forward(want_pred=False)
+    rel = np.abs(losses[:10] - d["losses"][:10]) / d["losses"][:10]
+    return 10 * math.log10(3 * H * W / sse), float(d["psnr"]), rel
+t = os.environ.get("SIREN_FIT_FP8_TARGET", "default")
+for fmt in (8,):
+    p1, r1, rel1 = fit("plateau_ns_256x8_256", so.nonsmooth_image(256, 256), 200, 40, fmt)
+    p2, r2, _ = fit("plateau_ns_256x8_256_1000", so.nonsmooth_image(256, 256), 1000, 200, fmt)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "horizon_256x8_128.npz"))
+    p3, r3, _ = fit("horizon_256x8_128", so.nonsmooth_image(128, 128), int(d["steps"]), int(d["lr_step"]), fmt)
+    print(f"target {t}: ns200 {p1:.3f} (ref {r1:.3f}) early rel {rel1[2]:.1e} {rel1[5]:.1e} {rel1[9]:.1e} | ns1000 {p2:.3f} (ref {r2:.3f}) | horizon {p3:.3f} (ref {r3:.3f})")
