@@ -583,12 +583,14 @@ int launch_wgemm(sf_engine* h, const WGemmArgs& a, int n_super, int n_ob) {
     else hipLaunchKernelGGL((k_wgemm<1, OpBF16>), dim3(grid), dim3(512), lds, h->stream, b);
   } else {
     const size_t lds = (size_t)4 * 32 * 1024;
-    int rc = f16 ? set_lds(k_wgemm2<MODE, OpF16>, lds) : set_lds(k_wgemm2<MODE, OpBF16>, lds);
+    const bool p8 = h->s8 && (MODE == 0 || b.Pprev);        // phase bytes (format 12; fp16 only: sf_create)
+    int rc = p8 ? set_lds(k_wgemm2<MODE, OpF16, true>, lds) : f16 ? set_lds(k_wgemm2<MODE, OpF16>, lds) : set_lds(k_wgemm2<MODE, OpBF16>, lds);
     if (rc) return rc;
     // persistent: one workgroup per CU (a multiple of 8 * n_ob, so XCD and output block are loop invariants)
     unsigned pgrid = (unsigned)(h->dw_wg / (8 * n_ob) * (8 * n_ob));
     if (pgrid == 0 || pgrid > grid) pgrid = grid;
-    if (f16) hipLaunchKernelGGL((k_wgemm2<MODE, OpF16>), dim3(pgrid), dim3(512), lds, h->stream, b);
+    if (p8) hipLaunchKernelGGL((k_wgemm2<MODE, OpF16, true>), dim3(pgrid), dim3(512), lds, h->stream, b);
+    else if (f16) hipLaunchKernelGGL((k_wgemm2<MODE, OpF16>), dim3(pgrid), dim3(512), lds, h->stream, b);
     else hipLaunchKernelGGL((k_wgemm2<MODE, OpBF16>), dim3(pgrid), dim3(512), lds, h->stream, b);
   }
   HIPCHK(hipGetLastError());
@@ -618,8 +620,9 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       memset(&a, 0, sizeof(a));
       a.gh = h->gh; a.gw = h->gw; a.W = h->cfg.width; a.row_begin = h->cfg.row_begin; a.pix0 = pix0; a.npix = h->npix;
       a.l0tab = h->l0tab; a.sc_first = sc_first; a.KS = KS; a.n_pieces = n_pb * KS; a.P = h->Pbuf; a.Act = h->Abuf;
-      Launch L(h, K_FWD, 4.0 * WD * npx, npx * (WD * 4.0));
-      if (f16) hipLaunchKernelGGL(k_wlayer0<OpF16>, dim3((unsigned)((a.n_pieces + 3) / 4)), dim3(256), 0, h->stream, a);
+      Launch L(h, K_FWD, 4.0 * WD * npx, npx * (WD * (h->s8 ? 3.0 : 4.0)));
+      if (h->s8) hipLaunchKernelGGL((k_wlayer0<OpF16, true>), dim3((unsigned)((a.n_pieces / 2 + 3) / 4)), dim3(256), 0, h->stream, a);
+      else if (f16) hipLaunchKernelGGL(k_wlayer0<OpF16>, dim3((unsigned)((a.n_pieces + 3) / 4)), dim3(256), 0, h->stream, a);
       else hipLaunchKernelGGL(k_wlayer0<OpBF16>, dim3((unsigned)((a.n_pieces + 3) / 4)), dim3(256), 0, h->stream, a);
       L.done();
       HIPCHK(hipGetLastError());
@@ -629,10 +632,10 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       memset(&a, 0, sizeof(a));
       a.A = reinterpret_cast<const u32x4*>(h->wf + (size_t)(l - 1) * WD * WD);
       a.a_block_pieces = (long)blk_pieces; a.n_chunk = KS / 4;
-      a.Bin = h->Abuf + (size_t)(l - 1) * h->p_stride; a.ks_in = KS;
+      a.Bin = h->Abuf + (size_t)(l - 1) * h->d_stride; a.ks_in = KS;
       a.bias = h->biasw + (size_t)(l - 1) * WD; a.sc = sc_hidden;
-      a.Out = h->Pbuf + (size_t)l * h->p_stride; a.OutAct = h->Abuf + (size_t)l * h->p_stride; a.ks_out = KS;
-      Launch L(h, K_FWD, 2.0 * WD * WD * npx, npx * (WD * 2.0 * (2 + NBLK)));
+      a.Out = h->Pbuf + (size_t)l * h->p_stride; a.OutAct = h->Abuf + (size_t)l * h->d_stride; a.ks_out = KS; a.kp_out = WD / 32;
+      Launch L(h, K_FWD, 2.0 * WD * WD * npx, npx * (WD * ((h->s8 ? 3.0 : 4.0) + 2.0 * NBLK)));
       rc = launch_wgemm<0>(h, a, n_super, NBLK);
       L.done();
       if (rc) return rc;
@@ -642,7 +645,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       memset(&a, 0, sizeof(a));
       a.A = reinterpret_cast<const u32x4*>(h->wf_last);
       a.a_block_pieces = (long)KS; a.n_chunk = KS / 4;
-      a.Bin = h->Abuf + (size_t)(D - 2) * h->p_stride; a.ks_in = KS;
+      a.Bin = h->Abuf + (size_t)(D - 2) * h->d_stride; a.ks_in = KS;
       a.bias = h->biasw + (size_t)(D - 2) * WD; a.sc = 1.0f / h->wscale;
       a.img = h->img; a.pred = pred; a.nout = h->cfg.out_features;
       a.gscale = (float)((double)h->gpre / ((double)h->cfg.out_features * h->n_total));
@@ -659,7 +662,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
     int n_wg = (int)(n_pb < (long)h->dw_wg ? n_pb : (long)h->dw_wg);
     for (int l = D - 1; l >= 1; --l) {
       const bool last = l == D - 1;
-      const u32x4* Dl = last ? h->Dlast : h->Dbuf + (size_t)l * h->p_stride;
+      const u32x4* Dl = last ? h->Dlast : h->Dbuf + (size_t)l * h->d_stride;
       const u32x4* Pprev = h->Pbuf + (size_t)(l - 1) * h->p_stride;
       {   // weight gradient: every [256 x 256] (last layer: [32 x 256]) block in one launch, blockIdx.y = block
         const int nby = (last ? 1 : NBLK) * NBLK;
@@ -668,7 +671,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
         if ((long)gx > n_pb) gx = (int)n_pb;
         WDwArgs a;
         memset(&a, 0, sizeof(a));
-        a.D = Dl; a.ksd_total = last ? 2 : KS; a.P = h->Abuf + (size_t)(l - 1) * h->p_stride; a.ksp_total = KS; a.nblk_i = NBLK;
+        a.D = Dl; a.ksd_total = last ? 2 : KS; a.P = h->Abuf + (size_t)(l - 1) * h->d_stride; a.ksp_total = KS; a.nblk_i = NBLK;
         a.n_pb = n_pb; a.slab = h->slab;
         const double rows = last ? h->cfg.out_features : WD;
         {
@@ -703,10 +706,10 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       a.A = last ? reinterpret_cast<const u32x4*>(h->wb_last) : reinterpret_cast<const u32x4*>(h->wb + (size_t)(l - 1) * WD * WD);
       a.a_block_pieces = last ? 32 : (long)blk_pieces; a.n_chunk = last ? 1 : KS / 4;
       a.Bin = Dl; a.ks_in = last ? 2 : KS;
-      a.Out = h->Dbuf + (size_t)(l - 1) * h->p_stride; a.ks_out = KS; a.Pprev = Pprev;
+      a.Out = h->Dbuf + (size_t)(l - 1) * h->d_stride; a.ks_out = KS; a.kp_out = WD / 32; a.Pprev = Pprev;
       const double rows = last ? h->cfg.out_features : WD;
       Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 2.0 * rows * WD * npx,
-               npx * ((last ? 64.0 : WD * 2.0 * NBLK) + WD * 4.0));
+               npx * ((last ? 64.0 : WD * 2.0 * NBLK) + WD * (h->s8 ? 3.0 : 4.0)));
       rc = launch_wgemm<2>(h, a, n_super, NBLK);
       L.done();
       if (rc) return rc;
@@ -968,8 +971,10 @@ int sf_create(const sf_config* cfg, sf_handle** out) try {
   if (cfg->height < 1 || cfg->width < 1) return fail(SF_ERR_INVALID, "bad image size");
   if (cfg->scratch_format != 0 && cfg->scratch_format != 8 && cfg->scratch_format != 12 && cfg->scratch_format != 16)
     return fail(SF_ERR_INVALID, "scratch_format must be 0 (auto), 8, 12 or 16");
-  if ((cfg->scratch_format == 8 || cfg->scratch_format == 12) && (cfg->hidden > 256 || cfg->compute_dtype != SF_F16))
-    return fail(SF_ERR_INVALID, "scratch_format 8 / 12 need hidden <= 256 and compute_dtype SF_F16");
+  if ((cfg->scratch_format == 8 || cfg->scratch_format == 12) && cfg->compute_dtype != SF_F16)
+    return fail(SF_ERR_INVALID, "scratch_format 8 / 12 need compute_dtype SF_F16");
+  if (cfg->scratch_format == 8 && cfg->hidden > 256)
+    return fail(SF_ERR_INVALID, "scratch_format 8 needs hidden <= 256 (the layer-at-a-time kernels of wider networks have phase bytes, format 12, only)");
   int r0 = cfg->row_begin, r1 = cfg->row_end;
   if (r0 == 0 && r1 == 0) r1 = cfg->height;
   if (r0 < 0 || r1 > cfg->height || r0 >= r1) return fail(SF_ERR_INVALID, "bad row range");
@@ -1006,7 +1011,9 @@ int sf_create(const sf_config* cfg, sf_handle** out) try {
     // launch-latency-bound and keep 16-bit deltas (format 12).  A masked fit is moved to format 16 by sf_set_masks.
     int fmt = cfg->scratch_format;
     h->fmt_auto = fmt == 0;
-    if (fmt == 0) fmt = (h->wide || cfg->compute_dtype != SF_F16) ? 16 : ((double)cfg->height * (double)cfg->width >= 1048576.0 ? 8 : 12);
+    const bool mega = (double)cfg->height * (double)cfg->width >= 1048576.0;
+    // (wider than 256: the layer-at-a-time kernels have phase bytes only, and take them where bandwidth matters - from 2^20 pixels)
+    if (fmt == 0) fmt = cfg->compute_dtype != SF_F16 ? 16 : h->wide ? (mega ? 12 : 16) : (mega ? 8 : 12);
     h->cfg.scratch_format = fmt;
     h->s8 = fmt == 8 || fmt == 12;
     h->d8 = fmt == 8;
@@ -1069,7 +1076,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) try {
   }
   ALLOC(h->gh, (size_t)cfg->height * 4); ALLOC(h->gw, (size_t)cfg->width * 4);
   ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->d_stride * 16);
-  if (h->wide) ALLOC(h->Abuf, (size_t)(D - 1) * h->p_stride * 16);
+  if (h->wide) ALLOC(h->Abuf, (size_t)(D - 1) * h->d_stride * 16);
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
   { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4 + 4096); }
   h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
@@ -1224,7 +1231,7 @@ int sf_set_masks(sf_handle* h, const float* p) try {
   if (!h) return fail(SF_ERR_INVALID, "null argument");
   DevGuard dev_guard(h->cfg.device);
   if (!p) { h->has_mask = false; return SF_OK; }
-  if (h->fmt_auto && !h->wide && h->cfg.scratch_format != 16) {
+  if (h->fmt_auto && h->cfg.scratch_format != 16) {
     const int rs = switch_scratch_format(h, 16);
     if (rs) return rs;
   }

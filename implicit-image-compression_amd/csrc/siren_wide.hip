@@ -80,29 +80,47 @@ struct WL0Args {
   const float* gh; const float* gw; int W, row_begin; long pix0, npix;
   const f32x4* l0tab; float sc_first; int KS; long n_pieces; u32x4* P; u32x4* Act;
 };
-template <typename OP2>
+// P8 (scratch_format 12 on the wide path, round 3): the phases are spilled as BYTES, one 1 KiB piece per (pixel block, 32-neuron
+// tile) - byte 8 q + j of lane (h, m) = neuron 32 tile + 16 q + PI(h, j), the layout of the width-256 path - so a wave takes
+// TWO k-steps (one tile): two activation pieces and one phase piece.  a.KS stays the number of 16-neuron k-steps.
+template <typename OP2, bool P8 = false>
 __global__ __launch_bounds__(256) void k_wlayer0(WL0Args a) {
-  const long piece = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (piece >= a.n_pieces) return;
+  constexpr int SPW = P8 ? 2 : 1;                      // k-steps per wave
+  const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit * SPW >= a.n_pieces) return;
   const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-  const long pb = piece / a.KS;
-  const int s = (int)(piece % a.KS);
+  const int upb = a.KS / SPW;                          // units per pixel block
+  const long pb = unit / upb;
+  const int s0 = (int)(unit % upb) * SPW;
   long pix = a.pix0 + pb * 32 + m;
   if (pix >= a.npix) pix = a.npix - 1;
   const int row = (int)(pix / a.W), col = (int)(pix - (long)row * a.W);
   const float x0 = (a.gh[a.row_begin + row] - 0.5f) * 2.0f, x1 = (a.gw[col] - 0.5f) * 2.0f;
-  float ph[8], av[8];
+  uint32_t pb8[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const f32x4 t = a.l0tab[16 * s + pi_perm(h, j)];
-    const float tt = __builtin_fmaf(t.y, x1, __builtin_fmaf(t.x, x0, t.z)) * a.sc_first;
-    ph[j] = __builtin_amdgcn_fractf(tt);
-    av[j] = __builtin_amdgcn_sinf(tt);
+  for (int q = 0; q < SPW; ++q) {
+    const int s = s0 + q;
+    float tv[8], ph[8], av[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 t = a.l0tab[16 * s + pi_perm(h, j)];
+      const float tt = __builtin_fmaf(t.y, x1, __builtin_fmaf(t.x, x0, t.z)) * a.sc_first;
+      tv[j] = tt;
+      ph[j] = __builtin_amdgcn_fractf(tt);
+      av[j] = __builtin_amdgcn_sinf(tt);
+    }
+    const long piece = pb * a.KS + s;
+    if constexpr (P8) {
+      pb8[2 * q] = phase_byte4(tv, av);
+      pb8[2 * q + 1] = phase_byte4(tv + 4, av + 4);
+    } else {
+      a.P[piece * 64 + lane] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
+                                     pack_phase2(ph[6], ph[7])};
+    }
+    a.Act[piece * 64 + lane] =
+        u32x4{OP2::pack2(av[0], av[1]), OP2::pack2(av[2], av[3]), OP2::pack2(av[4], av[5]), OP2::pack2(av[6], av[7])};
   }
-  a.P[piece * 64 + lane] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
-                                 pack_phase2(ph[6], ph[7])};
-  a.Act[piece * 64 + lane] =
-      u32x4{OP2::pack2(av[0], av[1]), OP2::pack2(av[2], av[3]), OP2::pack2(av[4], av[5]), OP2::pack2(av[6], av[7])};
+  if constexpr (P8) a.P[(pb * upb + s0 / 2) * 64 + lane] = u32x4{pb8[0], pb8[1], pb8[2], pb8[3]};
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -119,6 +137,7 @@ struct WGemmArgs {
   u32x4* Out;            // MODE 0: phases out, MODE 2: deltas out (F-layout, ks_out k-steps per block)
   u32x4* OutAct;         // MODE 0: activations out (same geometry as Out)
   int ks_out;
+  int kp_out;            // P8: phase-byte pieces per pixel block (= width / 32) of Out (MODE 0) / Pprev (MODE 2)
   const u32x4* Pprev;    // MODE 2: phases of the layer whose delta is produced (same geometry as Out)
   // MODE 1 (last layer)
   const float* img; float* pred; float gscale; float* sse_part; u32x4* Dlast; long pix0, npix;
@@ -260,11 +279,12 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
 // loading the 256-pixel input chunk once per workgroup (instead of once per wave pair, in registers) cuts the
 // L2 -> CU bytes by a third.  Chunk = 2 k-steps: 16 A pieces + 16 B pieces = 32 KiB per slot, 4 slots, staged
 // three chunks ahead (4 LDS-DMA instructions per wave per chunk, counted vmcnt).
-template <int MODE, typename OP>
+// P8: the phases are bytes (scratch_format 12, see k_wlayer0): one piece per (pixel block, 32-neuron tile) instead of two.
+template <int MODE, typename OP, bool P8 = false>
 __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
   static_assert(MODE == 0 || MODE == 2, "last layer: k_wgemm<1>");
   constexpr int OT = 8, TW = 4, PBW = 2, NB = 4, PD = 3, SLOT = 32 * 1024;
-  constexpr int NEP = MODE == 0 ? 2 * TW * PBW * 2 : TW * PBW * 2;   // epilogue stores per wave (phase + activation / delta)
+  constexpr int NEP = MODE == 0 ? TW * PBW * (P8 ? 3 : 4) : TW * PBW * 2;   // epilogue stores per wave (phase + activation / delta)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
     for (int t = 0; t < TW; ++t)
 #pragma unroll
       for (int p = 0; p < PBW; ++p) acc[t][p] = init[t];
-    u32x4 pv[TW][PBW][2];                                  // MODE 2: phases for the cos factor, requested early
+    u32x4 pv[TW][PBW][P8 ? 1 : 2];                         // MODE 2: phases for the cos factor, requested early
     for (int c = 0; c < n2; ++c) {
       // vmcnt is in-order: "chunk c landed" = all but the younger operations done; younger are the DMA of chunks
       // c+1, c+2 and - in the first PD steps of a tile that follows another - that tile's NEP epilogue stores
@@ -332,9 +352,13 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
         for (int t = 0; t < TW; ++t)
 #pragma unroll
           for (int p = 0; p < PBW; ++p)
+            if constexpr (P8) {
+              pv[t][p][0] = a.Pprev[((pb0 + p) * a.kp_out + 8 * ob + (t0 + t)) * 64 + lane];
+            } else {
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq)
-              pv[t][p][qq] = a.Pprev[((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane];
+              for (int qq = 0; qq < 2; ++qq)
+                pv[t][p][qq] = a.Pprev[((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane];
+            }
       }
       const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
       const u32x4* sB = sA + 16 * 64;
@@ -362,22 +386,31 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
 #pragma unroll
       for (int t = 0; t < TW; ++t)
 #pragma unroll
-        for (int p = 0; p < PBW; ++p)
+        for (int p = 0; p < PBW; ++p) {
+          uint32_t pb8[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
-            float ph[8], av[8];
+            float tv[8], ph[8], av[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float tt = acc[t][p][8 * qq + j];   // revolutions (scale folded into the image)
+              tv[j] = tt;
               ph[j] = __builtin_amdgcn_fractf(tt);
               av[j] = __builtin_amdgcn_sinf(tt);
             }
             const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane;
-            a.Out[pidx] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
-                                pack_phase2(ph[6], ph[7])};
+            if constexpr (P8) {
+              pb8[2 * qq] = phase_byte4(tv, av);
+              pb8[2 * qq + 1] = phase_byte4(tv + 4, av + 4);
+            } else {
+              a.Out[pidx] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
+                                  pack_phase2(ph[6], ph[7])};
+            }
             a.OutAct[pidx] = u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]),
                                    OP::pack2(av[6], av[7])};
           }
+          if constexpr (P8) a.Out[((pb0 + p) * a.kp_out + 8 * ob + (t0 + t)) * 64 + lane] = u32x4{pb8[0], pb8[1], pb8[2], pb8[3]};
+        }
     } else {
 #pragma unroll
       for (int t = 0; t < TW; ++t)
@@ -386,12 +419,21 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
             const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane;
-            const u32x4 pvv = pv[t][p][qq];
             u32x4 o;
+            if constexpr (P8) {
+              const u32x4 pvv = pv[t][p][0];
+              const uint32_t w0 = pvv[2 * qq], w1 = pvv[2 * qq + 1];     // bytes 8 qq .. 8 qq + 7
+              o[0] = OP::pack2(acc[t][p][8 * qq + 0] * __builtin_amdgcn_cosf(phase_rev8<0>(w0)), acc[t][p][8 * qq + 1] * __builtin_amdgcn_cosf(phase_rev8<1>(w0)));
+              o[1] = OP::pack2(acc[t][p][8 * qq + 2] * __builtin_amdgcn_cosf(phase_rev8<2>(w0)), acc[t][p][8 * qq + 3] * __builtin_amdgcn_cosf(phase_rev8<3>(w0)));
+              o[2] = OP::pack2(acc[t][p][8 * qq + 4] * __builtin_amdgcn_cosf(phase_rev8<0>(w1)), acc[t][p][8 * qq + 5] * __builtin_amdgcn_cosf(phase_rev8<1>(w1)));
+              o[3] = OP::pack2(acc[t][p][8 * qq + 6] * __builtin_amdgcn_cosf(phase_rev8<2>(w1)), acc[t][p][8 * qq + 7] * __builtin_amdgcn_cosf(phase_rev8<3>(w1)));
+            } else {
+              const u32x4 pvv = pv[t][p][qq];
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2)
-              o[j2] = OP::pack2(acc[t][p][8 * qq + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(pvv[j2])),
-                                acc[t][p][8 * qq + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(pvv[j2])));
+              for (int j2 = 0; j2 < 4; ++j2)
+                o[j2] = OP::pack2(acc[t][p][8 * qq + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(pvv[j2])),
+                                  acc[t][p][8 * qq + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(pvv[j2])));
+            }
             a.Out[pidx] = o;
           }
     }

@@ -13,8 +13,8 @@ from implicit_image._engine import SirenEngine  # noqa: E402
 from implicit_image.models import Siren  # noqa: E402
 
 
-def run(hidden, depth, size, steps=3, warm=1):
-    eng = SirenEngine(size, size, hidden, depth, compute_dtype="f16")
+def run(hidden, depth, size, steps=3, warm=1, fmt=0):
+    eng = SirenEngine(size, size, hidden, depth, compute_dtype="f16", scratch_format=fmt)
     torch.manual_seed(0)
     init = Siren(depth=depth, hidden_size=hidden, first_omega_0=50.0, hidden_omega_0=30.0)
     dev = torch.device("cuda")
@@ -32,7 +32,7 @@ def run(hidden, depth, size, steps=3, warm=1):
     rep = eng.profile_report()
     pw = 2 * hidden + (depth - 2) * hidden * hidden + 3 * hidden
     F = 6 * pw - 4 * hidden
-    out = {"hidden": hidden, "depth": depth, "size": size, "ms_per_step": dt * 1e3,
+    out = {"hidden": hidden, "depth": depth, "size": size, "scratch_format": eng.scratch_format, "ms_per_step": dt * 1e3,
            "Mpix_iters_per_s": size * size / dt / 1e6, "step_TFLOPs": size * size * F / dt / 1e12,
            "kernels": {k: {"ms_per_step": v["total_ms"] / steps, "launches": v["launches"] / steps,
                            "tflops": v["flops_per_launch"] * v["launches"] / max(v["total_ms"], 1e-9) / 1e9}
@@ -42,5 +42,7 @@ def run(hidden, depth, size, steps=3, warm=1):
 
 
 if __name__ == "__main__":
+    fmts = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]     # e.g. "16,12": both phase formats
     for hidden, depth, size in ((512, 8, 2048), (1024, 12, 1024)):
-        run(hidden, depth, size)
+        for fmt in fmts:
+            run(hidden, depth, size, fmt=fmt)
