@@ -23,6 +23,7 @@ from oracle import siren_oracle as so
 pytestmark = pytest.mark.gpu
 
 FORMATS = (16, 12, 8)
+NS1024_BOUND = {16: 0.05, 12: 0.05, 8: 0.05}   # BASELINE.json's criterion (measured: -0.011 / -0.010 / -0.024 dB)
 
 
 def _sha(a):
@@ -370,3 +371,18 @@ def test_wide_phase_bytes_psnr_parity_and_auto_rule():
     big.close()
     with pytest.raises(RuntimeError):
         SirenEngine(64, 64, 512, 3, scratch_format=8)
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_non_smooth_content_200_steps_at_a_megapixel(golden, fmt):
+    """The non-smooth fixture at 1024 x 1024 (the size from which format 8 is the auto format): reference 20.9104 dB, its own 8-
+    vs 2-thread spread 0.0000 dB.  The deviations of the 256 x 256 run (-0.10 / +0.68 / +0.01 dB) shrink with the pixel count,
+    as rounding noise summed over pixels does: measured here -0.011 / -0.010 / -0.024 dB for formats 16 / 12 / 8 - the 0.05 dB
+    criterion HOLDS on non-smooth content at the size where the byte formats are what the engine picks."""
+    d = golden("plateau_ns_256x8_1024")
+    assert float(d["psnr_spread"]) <= 0.01
+    lr_step = int(d["lr_step"])
+    psnr, losses = _fit(d, fmt, so.nonsmooth_image(1024, 1024), lambda t: 3e-4 * 0.5 ** (t // lr_step))
+    assert abs(psnr - float(d["psnr"])) <= NS1024_BOUND[fmt], (psnr, float(d["psnr"]))
+    rel = np.abs(losses[:10] - d["losses"][:10]) / d["losses"][:10]
+    assert np.max(rel[:3]) <= 5e-3
