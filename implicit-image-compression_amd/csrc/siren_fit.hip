@@ -582,6 +582,26 @@ int launch_wgemm(sf_engine* h, const WGemmArgs& a, int n_super, int n_ob) {
     if (f16) hipLaunchKernelGGL((k_wgemm<1, OpF16>), dim3(grid), dim3(512), lds, h->stream, b);
     else hipLaunchKernelGGL((k_wgemm<1, OpBF16>), dim3(grid), dim3(512), lds, h->stream, b);
   } else {
+    static const bool w4 = getenv("SIREN_FIT_WGEMM4") && atoi(getenv("SIREN_FIT_WGEMM4")) == 1;   // A/B knob: four-wave workgroups, two per CU
+    if (w4 && f16 && a.ks_in >= 8) {
+      b.n_super = 2 * n_super;                              // 128-pixel units
+      const size_t lds4 = (size_t)3 * 24 * 1024;
+      const unsigned grid4 = (unsigned)((b.n_super + 7) / 8 * 8 * n_ob);
+      unsigned pg = (unsigned)(2 * h->dw_wg / (8 * n_ob) * (8 * n_ob));
+      if (pg == 0 || pg > grid4) pg = grid4;
+      int rc;
+      if (h->s8) {
+        rc = set_lds(k_wgemm2<MODE, OpF16, true, 4>, lds4);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_wgemm2<MODE, OpF16, true, 4>), dim3(pg), dim3(256), lds4, h->stream, b);
+      } else {
+        rc = set_lds(k_wgemm2<MODE, OpF16, false, 4>, lds4);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_wgemm2<MODE, OpF16, false, 4>), dim3(pg), dim3(256), lds4, h->stream, b);
+      }
+      HIPCHK(hipGetLastError());
+      return SF_OK;
+    }
     const size_t lds = (size_t)4 * 32 * 1024;
     const bool p8 = h->s8 && (MODE == 0 || b.Pprev);        // phase bytes (format 12; fp16 only: sf_create)
     int rc = p8 ? set_lds(k_wgemm2<MODE, OpF16, true>, lds) : f16 ? set_lds(k_wgemm2<MODE, OpF16>, lds) : set_lds(k_wgemm2<MODE, OpBF16>, lds);

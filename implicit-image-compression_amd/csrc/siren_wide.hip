@@ -280,10 +280,17 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
 // L2 -> CU bytes by a third.  Chunk = 2 k-steps: 16 A pieces + 16 B pieces = 32 KiB per slot, 4 slots, staged
 // three chunks ahead (4 LDS-DMA instructions per wave per chunk, counted vmcnt).
 // P8: the phases are bytes (scratch_format 12, see k_wlayer0): one piece per (pixel block, 32-neuron tile) instead of two.
-template <int MODE, typename OP, bool P8 = false>
-__global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
+// NWV = 4 (round 3): the same tile plan with FOUR waves per workgroup - 256 neurons x 128 pixels, 24 KiB per chunk, a ring
+// of three - so that TWO workgroups share a CU (2 x 72 KiB of LDS, 2 waves per SIMD as before): they drift apart, and the
+// epilogue of one (128 sines per thread, matrix pipe idle) runs beside the main loop of the other.  a.n_super then counts
+// 128-pixel units.
+template <int MODE, typename OP, bool P8 = false, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs a) {
   static_assert(MODE == 0 || MODE == 2, "last layer: k_wgemm<1>");
-  constexpr int OT = 8, TW = 4, PBW = 2, NB = 4, PD = 3, SLOT = 32 * 1024;
+  static_assert(NWV == 8 || NWV == 4, "waves per workgroup");
+  constexpr int OT = 8, TW = 4, PBW = 2, NPB = NWV;              // pixel blocks per workgroup: two per wave pair
+  constexpr int NB = NWV == 8 ? 4 : 3, PD = NB - 1, SLOT = (16 + 2 * NPB) * 1024;
+  constexpr int GA = 16 / NWV, GB = 2 * NPB / NWV, G = GA + GB;   // LDS-DMA instructions per wave and chunk
   constexpr int NEP = MODE == 0 ? TW * PBW * (P8 ? 3 : 4) : TW * PBW * 2;   // epilogue stores per wave (phase + activation / delta)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -301,17 +308,18 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
   const u32x4* Ablk = a.A + (size_t)ob * a.a_block_pieces * 64;
   const int n2 = a.ks_in / 2;                            // chunks of 2 k-steps
   const bool pipe = n2 >= 4;                             // cross-tile prefetch (the K = 32 last-layer product: plain waits)
+  static_assert(PD == 2 || PD == 3, "the wait plan below");
   auto stage = [&](int tsb, int c) {
     char* base = smem + (c % NB) * SLOT;
-    const long pbg = (long)tsb * kWavesFwd;
+    const long pbg = (long)tsb * NPB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pc = wave + 8 * i, ot = pc >> 1, s2 = pc & 1;
+    for (int i = 0; i < GA; ++i) {
+      const int pc = wave + NWV * i, ot = pc >> 1, s2 = pc & 1;
       glds16s(Ablk + ((size_t)((c >> 1) * OT + ot) * 4 + 2 * (c & 1) + s2) * 64, (uint32_t)lane * 16u, base + pc * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pc = wave + 8 * i, p = pc >> 1, s2 = pc & 1;
+    for (int i = 0; i < GB; ++i) {
+      const int pc = wave + NWV * i, p = pc >> 1, s2 = pc & 1;
       glds16s(a.Bin + ((pbg + p) * a.ks_in + 2 * c + s2) * 64, (uint32_t)lane * 16u, base + (16 + pc) * 1024);
     }
   };
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
   for (int c = 0; c < PD && c < n2; ++c) stage(sb, c);
   bool first = true;
   while (true) {
-    const long pb0 = (long)sb * kWavesFwd + pw;
+    const long pb0 = (long)sb * NPB + pw;
     f32x16 acc[TW][PBW];
 #pragma unroll
     for (int t = 0; t < TW; ++t)
@@ -341,10 +349,12 @@ __global__ __launch_bounds__(512) void k_wgemm2(WGemmArgs a) {
     for (int c = 0; c < n2; ++c) {
       // vmcnt is in-order: "chunk c landed" = all but the younger operations done; younger are the DMA of chunks
       // c+1, c+2 and - in the first PD steps of a tile that follows another - that tile's NEP epilogue stores
+      // (in flight behind chunk c: min(PD - 1, n2 - 1 - c) chunks of G instructions each)
       if (!pipe) bar_all();
-      else if (c + 2 >= n2) { if (c + 1 < n2) bar_dma<4>(); else bar_all(); }
-      else if (first || c >= PD) bar_dma<8>();
-      else bar_dma<8 + NEP>();
+      else if (c + 1 >= n2) bar_all();
+      else if (PD == 3 && c + 2 >= n2) bar_dma<G>();
+      else if (first || c >= PD) bar_dma<(PD - 1) * G>();
+      else bar_dma<(PD - 1) * G + NEP>();
       if (c + PD < n2) stage(sb, c + PD);
       asm volatile("" ::: "memory");
       if (MODE == 2 && c == n2 - 1) {
