@@ -130,10 +130,17 @@ class Masking:
         torch.rand(*self.input_size)            # RNG draw of the sparse-FLOPs log line (core.py:248,384)
         logging.info(f"Achieved sparsity at init (w/o BN, bias): {self.baseline_nonzero / self.total_params:.4f}")
 
+    def _masked(self):
+        """(name, parameter, mask) of every masked parameter, in named_parameters() order - the order every per-layer loop
+        of the reference walks (float accumulations below depend on it)."""
+        for pname, par in self.module.named_parameters():
+            mk = self.mask_dict.get(pname)
+            if mk is not None:
+                yield pname, par, mk
+
     def _to_module_device(self):
-        for name, weight in self.module.named_parameters():
-            if name in self.mask_dict:
-                self.mask_dict[name] = self.mask_dict[name].to(weight.device)
+        for pname, par, mk in list(self._masked()):
+            self.mask_dict[pname] = mk.to(par.device)
 
     def flat_mask(self) -> torch.Tensor:
         """Current masks as one flat 0/1 vector in named_parameters() order (ones for unmasked parameters)."""
@@ -154,26 +161,23 @@ class Masking:
     # ---- per-step (core.py:271-289, 671-702) ------------------------------------------------
     @torch.no_grad()
     def apply_mask(self):
-        for name, weight in self.module.named_parameters():
-            if name in self.mask_dict:
-                weight.data.mul_(self.mask_dict[name].to(weight.dtype))
+        for _, par, mk in self._masked():
+            par.data.mul_(mk.to(par.dtype))
         self._push_masks()
 
     @torch.no_grad()
     def apply_mask_gradients(self):
-        for name, weight in self.module.named_parameters():
-            if name in self.mask_dict and weight.grad is not None:
-                weight.grad.mul_(self.mask_dict[name])
+        for _, par, mk in self._masked():
+            if par.grad is not None:
+                par.grad.mul_(mk)
 
     @torch.no_grad()
     def reset_momentum(self):
-        for name, weight in self.module.named_parameters():
-            if name not in self.mask_dict:
-                continue
-            st = self.optimizer.state[weight]
-            if "exp_avg" in st:
-                st["exp_avg"].mul_(self.mask_dict[name])
-                st["exp_avg_sq"].mul_(self.mask_dict[name])
+        for _, par, mk in self._masked():
+            st = self.optimizer.state[par]
+            for key in ("exp_avg", "exp_avg_sq"):
+                if key in st:
+                    st[key].mul_(mk)
 
     def step(self, scaler=None):
         """Optimiser step, then masks, then prune-rate decay (core.py:671-702).  `scaler` is accepted
@@ -194,67 +198,60 @@ class Masking:
 
     # ---- topology update (core.py:425-464, 250-269, 713-801) ----------------------------------
     def gather_statistics(self):
-        variance, nonzeros, zeros = {}, {}, {}
-        tot_var, tot_nz, tot_z = 0.0, 0, 0
-        redist = redistribute_registry[self.redistribution_mode]
-        for name, weight in self.module.named_parameters():
-            if name not in self.mask_dict:
-                continue
-            mask = self.mask_dict[name]
-            variance[name] = redist(self, name, weight, mask)
-            if not np.isnan(variance[name]):
-                tot_var += variance[name]
-            nonzeros[name] = int((mask == 1).sum().int().item())
-            zeros[name] = int((mask == 0).sum().int().item())
-            tot_nz += nonzeros[name]
-            tot_z += zeros[name]
-        assert tot_var, "Total variance is zero!"
-        for name in variance:
-            variance[name] /= tot_var
-        self.stats = LayerStats(variance_dict=variance, nonzeros_dict=nonzeros, zeros_dict=zeros,
-                                total_variance=tot_var, total_nonzero=tot_nz, total_zero=tot_z)
+        """Per-layer redistribution statistic (normalised to sum 1), live and pruned counts (core.py:425-464)."""
+        stat_of = redistribute_registry[self.redistribution_mode]
+        share, live, dead = {}, {}, {}
+        for pname, par, mk in self._masked():
+            share[pname] = stat_of(self, pname, par, mk)
+            live[pname] = int((mk == 1).sum().int().item())
+            dead[pname] = int((mk == 0).sum().int().item())
+        norm = 0.0
+        for v in share.values():               # (summed in layer order; NaN statistics are skipped, as the reference does)
+            if not np.isnan(v):
+                norm += v
+        assert norm, "Total variance is zero!"
+        share = {k: v / norm for k, v in share.items()}
+        self.stats = LayerStats(variance_dict=share, nonzeros_dict=live, zeros_dict=dead, total_variance=norm,
+                                total_nonzero=sum(live.values()), total_zero=sum(dead.values()))
 
     def adjust_prune_rate(self):
-        for name, mask in self.mask_dict.items():
-            self.name2prune_rate[name] = self.prune_rate
-            sparsity = self.stats.zeros_dict[name] / mask.numel()
-            if sparsity < 0.2:
-                expected = 1.0 / len(self.stats.variance_dict)
-                if expected / self.stats.variance_dict[name] < 1.0:
-                    self.name2prune_rate[name] = min(sparsity, self.name2prune_rate[name])
+        """Layers that are still less than 20 % sparse and hold more than an equal share of the statistic are not pruned
+        beyond their own sparsity (core.py:250-269)."""
+        rate, fair = self.prune_rate, 1.0 / max(len(self.stats.variance_dict), 1)
+        for pname, mk in self.mask_dict.items():
+            frac_dead = self.stats.zeros_dict[pname] / mk.numel()
+            capped = frac_dead < 0.2 and fair / self.stats.variance_dict[pname] < 1.0
+            self.name2prune_rate[pname] = min(frac_dead, rate) if capped else rate
 
     @torch.no_grad()
     def truncate_weights(self):
         self.gather_statistics()
         self.adjust_prune_rate()
-        prune = prune_registry[self.prune_mode]
+        # 1. prune (core.py:713-745)
+        prune_fn = prune_registry[self.prune_mode]
         if self.global_prune:
-            self.stats.total_removed = prune(self)
+            self.stats.total_removed = prune_fn(self)
         else:
-            for name, weight in self.module.named_parameters():
-                if name not in self.mask_dict:
-                    continue
-                new_mask = prune(self, self.mask_dict[name], weight, name)
-                removed = self.stats.nonzeros_dict[name] - int(new_mask.sum().item())
-                self.stats.total_removed += removed
-                self.stats.removed_dict[name] = removed
-                self.mask_dict[name] = new_mask
-        total_nonzero_new = 0
+            for pname, par, mk in list(self._masked()):
+                kept = prune_fn(self, mk, par, pname)
+                gone = self.stats.nonzeros_dict[pname] - int(kept.sum().item())
+                self.stats.removed_dict[pname] = gone
+                self.stats.total_removed += gone
+                self.mask_dict[pname] = kept
+        # 2. grow (core.py:747-779): each layer regrows what it lost, or its share of the pool when a redistribution
+        #    statistic is active
         if self.growth_mode == "none":
             total_nonzero_new = self.stats.total_nonzero - self.stats.total_removed
         else:
-            grow = grow_registry[self.growth_mode]
-            redistribute = self.redistribution_mode not in ["nonzero", "none"]
-            if redistribute:
-                name2regrowth = self.calc_redistributed_densities()
-            for name, weight in self.module.named_parameters():
-                if name not in self.mask_dict:
-                    continue
-                num_growth = name2regrowth[name] if redistribute else self.stats.removed_dict[name]
-                new_mask = grow(self, name, num_growth, weight)
-                total_nonzero_new += new_mask.sum().item()
-                self.mask_dict.pop(name)
-                self.mask_dict[name] = new_mask.float()
+            grow_fn = grow_registry[self.growth_mode]
+            budgets = (self.calc_redistributed_densities() if self.redistribution_mode not in ("nonzero", "none")
+                       else self.stats.removed_dict)
+            total_nonzero_new = 0
+            for pname, par, _ in list(self._masked()):
+                grown = grow_fn(self, pname, budgets[pname], par)
+                total_nonzero_new += grown.sum().item()
+                del self.mask_dict[pname]                 # (re-inserted at the end: the reference's dict order after an update)
+                self.mask_dict[pname] = grown.float()
         self.apply_mask()
         if not self.dense_gradients:
             self.reset_momentum()

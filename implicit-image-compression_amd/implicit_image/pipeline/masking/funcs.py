@@ -13,89 +13,74 @@ import torch
 # funcs/init_scheme.py:40-158  Erdos-Renyi(-Kernel) densities and random masks
 # ---------------------------------------------------------------------------------------------
 def erdos_renyi_densities(shapes: Dict[str, torch.Size], density: float, is_kernel: bool = True) -> Dict[str, float]:
-    """Per-layer keep-probability eps * (sum(shape) / prod(shape)); layers whose probability would
-    exceed 1 are made dense one maximum at a time and eps is re-solved (init_scheme.py:66-129)."""
-    dense = set()
+    """Per-layer keep-probability eps * score, score = sum(shape) / prod(shape) (kernel form) or (n_in + n_out) / (n_in *
+    n_out); eps is solved so that the expected number of ones equals the budget, and while the largest score times eps
+    exceeds 1 the layers holding that score are made dense and eps is solved again (reference behaviour:
+    init_scheme.py:66-129; the integer truncations of the budget terms are the reference's and decide eps to the last bit)."""
+    sizes = {n: int(np.prod(sh)) for n, sh in shapes.items()}
+    score = {n: float(np.sum(sh) / np.prod(sh)) if is_kernel else (sh[0] + sh[1]) / (sh[0] * sh[1]) for n, sh in shapes.items()}
+    full = set()
     while True:
-        divisor, rhs, raw = 0.0, 0.0, {}
-        for name, shape in shapes.items():
-            n_param = int(np.prod(shape))
-            n_zeros = int(n_param * (1 - density))
-            n_ones = int(n_param * density)
-            if name in dense:
-                rhs -= n_zeros
+        budget, weight_sum = 0.0, 0.0
+        for n in shapes:                                     # (accumulated in layer order: float sums)
+            if n in full:
+                budget -= int(sizes[n] * (1 - density))      # a dense layer spends the zeros it was entitled to
             else:
-                rhs += n_ones
-                if is_kernel:
-                    raw[name] = float(np.sum(shape) / np.prod(shape))
-                else:
-                    n_in, n_out = shape[:2]
-                    raw[name] = (n_in + n_out) / (n_in * n_out)
-                divisor += raw[name] * n_param
-        eps = rhs / divisor
-        max_prob = max(raw.values())
-        if max_prob * eps > 1:
-            dense.update(n for n, p in raw.items() if p == max_prob)
-        else:
-            break
-    return {name: (1.0 if name in dense else eps * raw[name]) for name in shapes}
+                budget += int(sizes[n] * density)
+                weight_sum += score[n] * sizes[n]
+        eps = budget / weight_sum
+        open_scores = [score[n] for n in shapes if n not in full]
+        top = max(open_scores)
+        if top * eps <= 1:
+            return {n: 1.0 if n in full else eps * score[n] for n in shapes}
+        full.update(n for n in shapes if n not in full and score[n] == top)
+
+
+def _draw_masks(masking, make_mask, skip_first: bool = False):
+    """Walk the masked parameters in named_parameters() order, install make_mask(name, parameter) and book the counts."""
+    for pos, (pname, par) in enumerate(masking.module.named_parameters()):
+        if skip_first and pos == 0:
+            masking.mask_dict.pop(pname, None)
+            continue
+        if pname in masking.mask_dict:
+            mk = make_mask(pname, par)
+            masking.mask_dict[pname] = mk
+            masking.baseline_nonzero += int((mk != 0).sum().item())
+            masking.total_params += par.numel()
 
 
 def erk_init(masking, is_kernel: bool = True, **_):
-    """init_scheme.py:147-158: masks drawn on the CPU generator in named_parameters() order."""
-    shapes = {n: masking.mask_dict[n].shape for n in masking.mask_dict}
-    probs = erdos_renyi_densities(shapes, masking.density, is_kernel)
-    for name, weight in masking.module.named_parameters():
-        if name not in masking.mask_dict:
-            continue
-        masking.mask_dict[name] = (torch.rand(weight.shape) < probs[name]).float()
-        masking.baseline_nonzero += int((masking.mask_dict[name] != 0).sum().item())
-        masking.total_params += weight.numel()
+    """init_scheme.py:147-158: Bernoulli(prob_layer) masks drawn on the CPU generator in named_parameters() order."""
+    probs = erdos_renyi_densities({n: m.shape for n, m in masking.mask_dict.items()}, masking.density, is_kernel)
+    _draw_masks(masking, lambda pname, par: (torch.rand(par.shape) < probs[pname]).float())
     masking.erk_probs = probs
 
 
 def random_init(masking, **_):
-    """init_scheme.py:181-206: every layer keeps `density` of its weights at random; the FIRST parameter is
-    taken out of the mask set altogether (stays dense)."""
-    for e, (name, weight) in enumerate(masking.module.named_parameters()):
-        if e == 0:
-            masking.mask_dict.pop(name, None)
-            continue
-        if name not in masking.mask_dict:
-            continue
-        masking.mask_dict[name] = (torch.rand(weight.shape) < masking.density).float()
-        masking.baseline_nonzero += int(masking.mask_dict[name].sum().int().item())
-        masking.total_params += weight.numel()
+    """init_scheme.py:181-206: every layer keeps `density` of its weights at random; the FIRST parameter is taken out of the
+    mask set altogether (stays dense)."""
+    _draw_masks(masking, lambda pname, par: (torch.rand(par.shape) < masking.density).float(), skip_first=True)
 
 
 def resume_init(masking, **_):
     """init_scheme.py:209-228: mask = currently non-zero weights."""
-    for name, weight in masking.module.named_parameters():
-        if name not in masking.mask_dict:
-            continue
-        masking.mask_dict[name] = (weight != 0.0).float().cpu()
-        masking.baseline_nonzero += int(masking.mask_dict[name].sum().int().item())
-        masking.total_params += weight.numel()
+    _draw_masks(masking, lambda pname, par: (par != 0.0).float().cpu())
 
 
-init_registry = {
-    "erdos-renyi-kernel": erk_init,
-    "erdos-renyi": lambda m, **kw: erk_init(m, is_kernel=False, **kw),
-    "random": random_init,
-    "resume": resume_init,
-}
+init_registry = {"erdos-renyi-kernel": erk_init, "erdos-renyi": lambda m, **kw: erk_init(m, is_kernel=False, **kw),
+                 "random": random_init, "resume": resume_init}
 
 
 # ---------------------------------------------------------------------------------------------
 # funcs/prune.py:24-51  magnitude pruning
 # ---------------------------------------------------------------------------------------------
 def magnitude_prune(masking, mask: torch.Tensor, weight: torch.Tensor, name: str) -> torch.Tensor:
-    num_remove = math.ceil(masking.name2prune_rate[name] * masking.stats.nonzeros_dict[name])
-    if num_remove == 0.0:
-        return mask
-    k = masking.stats.zeros_dict[name] + num_remove
-    _, idx = torch.sort(torch.abs(weight.data.view(-1)))
-    mask.data.view(-1)[idx[:k]] = 0.0
+    """prune.py:24-51: the ceil(rate * live) smallest |w| among the live weights go (the already-masked weights are zero
+    and sort first, hence the offset by the dead count)."""
+    drop = math.ceil(masking.name2prune_rate[name] * masking.stats.nonzeros_dict[name])
+    if drop:
+        order = torch.sort(weight.data.abs().view(-1)).indices
+        mask.data.view(-1)[order[: masking.stats.zeros_dict[name] + drop]] = 0.0
     return mask
 
 
@@ -145,42 +130,39 @@ prune_registry = {"magnitude": magnitude_prune, "global-magnitude": global_magni
 # funcs/grow.py:58-97  absolute-gradient growth (grown weights start at 0)
 # ---------------------------------------------------------------------------------------------
 def abs_grad_growth(masking, name: str, total_regrowth: int, weight: torch.Tensor) -> torch.Tensor:
-    new_mask = masking.mask_dict[name].data.bool()
-    if int((new_mask == 0).sum().item()) == 0:
-        return new_mask
-    grad = weight.grad * (new_mask == 0).to(weight.grad.dtype)
-    _, idx = torch.sort(torch.abs(grad).flatten(), descending=True)
-    sel = idx[: int(total_regrowth)]
-    new_mask.data.view(-1)[sel] = True
-    weight.data.view(-1)[sel] = 0.0
-    return new_mask
+    live = masking.mask_dict[name].data.bool()
+    if bool(live.all()):
+        return live
+    candidates = weight.grad.abs() * (~live).to(weight.grad.dtype)          # |dL/dw| where the weight is masked out
+    pick = torch.sort(candidates.flatten(), descending=True).indices[: int(total_regrowth)]
+    live.view(-1)[pick] = True
+    weight.data.view(-1)[pick] = 0.0
+    return live
 
 
 def momentum_growth(masking, name: str, total_regrowth: int, weight: torch.Tensor) -> torch.Tensor:
     """grow.py:25-55: grow where |Adam momentum| = |m / (sqrt(v) + 1e-8)| is largest among masked-out entries
     (the weights themselves are NOT reset by this mode)."""
-    new_mask = masking.mask_dict[name].data.bool()
-    momentum = masking.get_momentum_for_weight(weight)
-    momentum = momentum * (new_mask == 0).to(momentum.dtype)
-    _, idx = torch.sort(torch.abs(momentum).flatten(), descending=True)
-    new_mask.data.view(-1)[idx[: int(total_regrowth)]] = True
-    return new_mask
+    live = masking.mask_dict[name].data.bool()
+    mom = masking.get_momentum_for_weight(weight)
+    candidates = (mom * (~live).to(mom.dtype)).abs()
+    live.view(-1)[torch.sort(candidates.flatten(), descending=True).indices[: int(total_regrowth)]] = True
+    return live
 
 
 def random_growth(masking, name: str, total_regrowth: int, weight: torch.Tensor) -> torch.Tensor:
     """grow.py:100-136: Bernoulli(total_regrowth / #zeros) growth among masked-out entries (device RNG of the
     mask tensor); grown and still-masked weights are zeroed."""
-    new_mask = masking.mask_dict[name].data.bool()
-    n = (new_mask == 0).sum().item()
-    if n == 0:
-        return new_mask
-    prob = total_regrowth / n
-    new_weights = torch.zeros_like(new_mask).bool()
-    new_weights[new_mask == 0] = torch.rand_like(new_weights[new_mask == 0].float()) < prob
-    new_mask = new_mask.bool() | new_weights.bool()
-    weight.data[new_weights == 1] = 0.0
-    weight.data[new_mask == 0] = 0.0
-    return new_mask
+    live = masking.mask_dict[name].data.bool()
+    free = int((~live).sum().item())
+    if free == 0:
+        return live
+    born = torch.zeros_like(live)
+    born[~live] = torch.rand_like(born[~live].float()) < total_regrowth / free
+    live = live | born
+    weight.data[born] = 0.0
+    weight.data[~live] = 0.0
+    return live
 
 
 def no_growth(masking, name: str, total_regrowth: int, weight: torch.Tensor) -> torch.Tensor:
