@@ -1,3 +1,4 @@
+"""End PSNR of three format-8 fits (non-smooth 200 / 1000 steps, long horizon) under SIREN_FIT_FP8_TARGET - the sweep behind kFp8Target."""
 import os, sys, math
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
