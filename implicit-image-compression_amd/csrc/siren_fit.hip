@@ -111,6 +111,7 @@ struct sf_engine {
   bool d8 = false;        // fp8 deltas under a per-chunk adaptive pre-scale (scratch_format 8)
   bool fmt_auto = false;  // scratch_format was 0 at sf_create: the engine picks it, and moves to 16 when a mask is set
   long d_stride = 0;      // pieces per layer in the delta scratch (p_stride: phases)
+  long a_stride = 0;      // wide path: pieces per layer in the activation scratch (always 16-bit)
   KmWs* km_ws = nullptr;        // sf_kmeans_fit workspace (allocated on first use)
   char* pad8 = nullptr;         // k_bwd8h: 1 KiB of zeros, then (at +8 KiB) an 8 KiB dump
   float* scale_dev = nullptr;   // {gpre / n_values_total, 1 / gpre} as the kernels read them (adaptive when s8)
@@ -547,9 +548,20 @@ int refresh_images_wide(sf_engine* h) {
     if (n < WD) n = WD;
     hipLaunchKernelGGL(k_wtables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, t);
   }
+  if (h->d8 && h->lsc) {   // per-layer fp8 delta scales (k_fp8_norms / k_fp8_links, as at width <= 256)
+    Fp8ScaleArgs f;
+    memset(&f, 0, sizeof(f));
+    f.params = h->params; f.depth = h->D; f.WD = h->WD; f.out_features = h->cfg.out_features;
+    for (int l = 0; l < h->D; ++l) f.off_w[l] = h->off_w[l];
+    f.om_first = h->cfg.first_omega_0; f.om_hidden = h->cfg.hidden_omega_0; f.link = h->lsc; f.inv = h->lsc + 16;
+    f.nrm = reinterpret_cast<double*>(h->lsc + 32);
+    hipLaunchKernelGGL(k_fp8_norms, dim3(h->D - 1), dim3(1024), 0, h->stream, f);
+    hipLaunchKernelGGL(k_fp8_links, dim3(1), dim3(64), 0, h->stream, f);
+  }
   auto image = [&](int l, bool transpose, int OT, int n_ob, int n_chunk, float scale, uint16_t* dst) {
     WImgArgs a;
     memset(&a, 0, sizeof(a));
+    a.link = (transpose && h->d8 && h->lsc) ? h->lsc + l : nullptr;
     a.W = h->params + h->off_w[l];
     a.rows = l == D - 1 ? h->cfg.out_features : WD; a.cols = WD;
     a.transpose = transpose; a.OT = OT; a.n_ob = n_ob; a.n_chunk = n_chunk; a.scale = scale; a.f16 = f16; a.dst = dst;
@@ -582,6 +594,25 @@ int launch_wgemm(sf_engine* h, const WGemmArgs& a, int n_super, int n_ob) {
     if (f16) hipLaunchKernelGGL((k_wgemm<1, OpF16>), dim3(grid), dim3(512), lds, h->stream, b);
     else hipLaunchKernelGGL((k_wgemm<1, OpBF16>), dim3(grid), dim3(512), lds, h->stream, b);
   } else {
+    if constexpr (MODE == 2) {
+      if (h->d8) {   // fp8 deltas (format 8): out always, in for every launch below the last layer's
+        const size_t lds8 = (size_t)4 * 32 * 1024;
+        unsigned pg8 = (unsigned)(h->dw_wg / (8 * n_ob) * (8 * n_ob));
+        if (pg8 == 0 || pg8 > grid) pg8 = grid;
+        int rc;
+        if (a.fscale) {
+          rc = set_lds(k_wgemm2<2, OpF16, true, 8, false, true>, lds8);
+          if (rc) return rc;
+          hipLaunchKernelGGL((k_wgemm2<2, OpF16, true, 8, false, true>), dim3(pg8), dim3(512), lds8, h->stream, b);
+        } else {
+          rc = set_lds(k_wgemm2<2, OpF16, true, 8, true, true>, lds8);
+          if (rc) return rc;
+          hipLaunchKernelGGL((k_wgemm2<2, OpF16, true, 8, true, true>), dim3(pg8), dim3(512), lds8, h->stream, b);
+        }
+        HIPCHK(hipGetLastError());
+        return SF_OK;
+      }
+    }
     static const bool w4 = getenv("SIREN_FIT_WGEMM4") && atoi(getenv("SIREN_FIT_WGEMM4")) == 1;   // A/B knob: four-wave workgroups, two per CU
     if (w4 && f16 && a.ks_in >= 8) {
       b.n_super = 2 * n_super;                              // 128-pixel units
@@ -652,9 +683,9 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       memset(&a, 0, sizeof(a));
       a.A = reinterpret_cast<const u32x4*>(h->wf + (size_t)(l - 1) * WD * WD);
       a.a_block_pieces = (long)blk_pieces; a.n_chunk = KS / 4;
-      a.Bin = h->Abuf + (size_t)(l - 1) * h->d_stride; a.ks_in = KS;
+      a.Bin = h->Abuf + (size_t)(l - 1) * h->a_stride; a.ks_in = KS;
       a.bias = h->biasw + (size_t)(l - 1) * WD; a.sc = sc_hidden;
-      a.Out = h->Pbuf + (size_t)l * h->p_stride; a.OutAct = h->Abuf + (size_t)l * h->d_stride; a.ks_out = KS; a.kp_out = WD / 32;
+      a.Out = h->Pbuf + (size_t)l * h->p_stride; a.OutAct = h->Abuf + (size_t)l * h->a_stride; a.ks_out = KS; a.kp_out = WD / 32;
       Launch L(h, K_FWD, 2.0 * WD * WD * npx, npx * (WD * ((h->s8 ? 3.0 : 4.0) + 2.0 * NBLK)));
       rc = launch_wgemm<0>(h, a, n_super, NBLK);
       L.done();
@@ -665,7 +696,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       memset(&a, 0, sizeof(a));
       a.A = reinterpret_cast<const u32x4*>(h->wf_last);
       a.a_block_pieces = (long)KS; a.n_chunk = KS / 4;
-      a.Bin = h->Abuf + (size_t)(D - 2) * h->d_stride; a.ks_in = KS;
+      a.Bin = h->Abuf + (size_t)(D - 2) * h->a_stride; a.ks_in = KS;
       a.bias = h->biasw + (size_t)(D - 2) * WD; a.sc = 1.0f / h->wscale;
       a.img = h->img; a.pred = pred; a.nout = h->cfg.out_features;
       a.gscale = (float)((double)h->gpre / ((double)h->cfg.out_features * h->n_total));
@@ -680,8 +711,13 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
     if (!train) continue;
     // ---- backward ----
     int n_wg = (int)(n_pb < (long)h->dw_wg ? n_pb : (long)h->dw_wg);
+    if (h->d8)   // fp8 deltas: this chunk's power-of-two factor from its own residual
+      hipLaunchKernelGGL(k_wchunk_scale, dim3(1), dim3(256), 0, h->stream, (const float*)(h->sse_part + sse_off - n_super), n_super,
+                         1.0 / ((double)h->cfg.out_features * (double)px), (float)((double)h->gpre / ((double)h->cfg.out_features * h->n_total)),
+                         h->gpre, fp8_target(), h->scale_dev);
     for (int l = D - 1; l >= 1; --l) {
       const bool last = l == D - 1;
+      const bool dl8 = h->d8 && !last;                      // this layer's incoming deltas are fp8 byte pieces
       const u32x4* Dl = last ? h->Dlast : h->Dbuf + (size_t)l * h->d_stride;
       const u32x4* Pprev = h->Pbuf + (size_t)(l - 1) * h->p_stride;
       {   // weight gradient: every [256 x 256] (last layer: [32 x 256]) block in one launch, blockIdx.y = block
@@ -691,7 +727,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
         if ((long)gx > n_pb) gx = (int)n_pb;
         WDwArgs a;
         memset(&a, 0, sizeof(a));
-        a.D = Dl; a.ksd_total = last ? 2 : KS; a.P = h->Abuf + (size_t)(l - 1) * h->d_stride; a.ksp_total = KS; a.nblk_i = NBLK;
+        a.D = Dl; a.ksd_total = last ? 2 : (dl8 ? WD / 32 : KS); a.P = h->Abuf + (size_t)(l - 1) * h->a_stride; a.ksp_total = KS; a.nblk_i = NBLK;
         a.n_pb = n_pb; a.slab = h->slab;
         const double rows = last ? h->cfg.out_features : WD;
         {
@@ -704,6 +740,12 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
     hipLaunchKernelGGL((k_wdw<JWv, OPv>), dim3(gx, nby), dim3(512), lds, h->stream, a);          \
   } while (0)
           if (last) { if (f16) SF_WDW(32, OpF16); else SF_WDW(32, OpBF16); }
+          else if (dl8) {
+            const size_t lds8 = (size_t)4 * (8 + 16) * 1024;
+            rc = set_lds(k_wdw<256, OpF16, true>, lds8);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_wdw<256, OpF16, true>), dim3(gx, nby), dim3(512), lds8, h->stream, a);
+          }
           else { if (f16) SF_WDW(256, OpF16); else SF_WDW(256, OpBF16); }
 #undef SF_WDW
           L.done();
@@ -714,6 +756,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
         r.slab = h->slab; r.n_wg = gx; r.slab_rows = last ? 32 : 256; r.rows_out = last ? h->cfg.out_features : 256;
         r.nblk_i = NBLK; r.gW = h->grads + h->off_w[l]; r.ldw = WD; r.gb = h->grads + h->off_b[l];
         r.accumulate = c > 0; r.scale = 1.0f / h->gpre;
+        if (dl8) { r.s1 = h->scale_dev; r.s2 = h->lsc + 16 + l; }
         const int n = r.rows_out * 256 + r.rows_out;
         Launch L(h, K_REDUCE, 0, (double)gx * nby * n * 4.0);
         hipLaunchKernelGGL(k_wreduce, dim3((n + 255) / 256, nby), dim3(256), 0, h->stream, r);
@@ -727,6 +770,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       a.a_block_pieces = last ? 32 : (long)blk_pieces; a.n_chunk = last ? 1 : KS / 4;
       a.Bin = Dl; a.ks_in = last ? 2 : KS;
       a.Out = h->Dbuf + (size_t)(l - 1) * h->d_stride; a.ks_out = KS; a.kp_out = WD / 32; a.Pprev = Pprev;
+      a.fscale = (h->d8 && last) ? h->scale_dev : nullptr;
       const double rows = last ? h->cfg.out_features : WD;
       Launch L(h, last ? K_BWD_LAST : K_BWD_HIDDEN, 2.0 * rows * WD * npx,
                npx * ((last ? 64.0 : WD * 2.0 * NBLK) + WD * (h->s8 ? 3.0 : 4.0)));
@@ -742,7 +786,12 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       da.inv_hm1 = h->cfg.height > 1 ? 1.0f / (float)(h->cfg.height - 1) : 0.f;
       da.inv_wm1 = h->cfg.width > 1 ? 1.0f / (float)(h->cfg.width - 1) : 0.f;
       da.w_magic = ((1ULL << 40) + (unsigned long long)h->cfg.width - 1) / (unsigned long long)h->cfg.width;
-      {
+      if (h->d8) {
+        Launch L(h, K_DW_FIRST, 4.0 * 256 * npx, 256.0 * npx);
+        rc = launch_dw0_8_t<256>(h, da, n_wg);
+        L.done();
+        if (rc) return rc;
+      } else {
         Launch L(h, K_DW_FIRST, 4.0 * 256 * npx, 512.0 * npx);
         const size_t lds = (size_t)8 * 16 * 1024 + 512;
         rc = f16 ? set_lds(k_dw0<256, OpF16>, lds) : set_lds(k_dw0<256, OpBF16>, lds);
@@ -755,6 +804,7 @@ int run_pass_wide(sf_engine* h, bool train, float* pred, bool want_sse) {
       ReduceArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.slab = h->slab; ra.n_wg = n_wg; ra.accumulate = c > 0; ra.scale = 1.0f / h->gpre; ra.scale_dev = nullptr;
+      if (h->d8) { ra.scale_dev = h->scale_dev; ra.scale2_dev = h->lsc + 16; }     // 1 / (chunk factor * gpre), 1 / cumulative layer scale
       ra.gW = h->grads + h->off_w[0] + 512 * jb; ra.gb = h->grads + h->off_b[0] + 256 * jb;
       ra.slab_rows = 256; ra.slab_cols = 32; ra.rows_out = 256; ra.cols_out = 2; ra.mode = 1;
       const int n = 256 * 3;
@@ -993,8 +1043,6 @@ int sf_create(const sf_config* cfg, sf_handle** out) try {
     return fail(SF_ERR_INVALID, "scratch_format must be 0 (auto), 8, 12 or 16");
   if ((cfg->scratch_format == 8 || cfg->scratch_format == 12) && cfg->compute_dtype != SF_F16)
     return fail(SF_ERR_INVALID, "scratch_format 8 / 12 need compute_dtype SF_F16");
-  if (cfg->scratch_format == 8 && cfg->hidden > 256)
-    return fail(SF_ERR_INVALID, "scratch_format 8 needs hidden <= 256 (the layer-at-a-time kernels of wider networks have phase bytes, format 12, only)");
   int r0 = cfg->row_begin, r1 = cfg->row_end;
   if (r0 == 0 && r1 == 0) r1 = cfg->height;
   if (r0 < 0 || r1 > cfg->height || r0 >= r1) return fail(SF_ERR_INVALID, "bad row range");
@@ -1096,7 +1144,7 @@ int sf_create(const sf_config* cfg, sf_handle** out) try {
   }
   ALLOC(h->gh, (size_t)cfg->height * 4); ALLOC(h->gw, (size_t)cfg->width * 4);
   ALLOC(h->Pbuf, (size_t)(D - 1) * h->p_stride * 16); ALLOC(h->Dbuf, (size_t)(D - 1) * h->d_stride * 16);
-  if (h->wide) ALLOC(h->Abuf, (size_t)(D - 1) * h->d_stride * 16);
+  if (h->wide) ALLOC(h->Abuf, (size_t)(D - 1) * h->a_stride * 16);
   ALLOC(h->Dlast, (size_t)chunk / 32 * 2 * 64 * 16);
   { const size_t sw = WD > 256 ? 256 : WD; ALLOC(h->slab, (size_t)h->dw_wg * (sw * sw + sw) * 4 + 4096); }
   h->n_sse = npix_pad / kSuper + (h->npix + chunk - 1) / chunk + 8;
@@ -1218,6 +1266,7 @@ static void set_scratch_strides(sf_engine* h) {
   const int WD = h->WD;
   h->p_stride = chunk / 32 * (h->s8 ? WD / 32 : WD / 16) * 64 + 37 * 64;
   h->d_stride = chunk / 32 * (h->d8 ? WD / 32 : WD / 16) * 64 + 37 * 64;
+  h->a_stride = chunk / 32 * (WD / 16) * 64 + 37 * 64;
 }
 // An auto-format handle that receives a mask leaves the 8-bit scratch: fp8 deltas under one scale per chunk underflow in
 // a 90 %-sparse network, and topology updates rank small gradients that phase bytes blur.

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(JW * 2) void k_dw0_8(Dw0Args a) {
   auto stage = [&](int k) {
     const long pb = pb_begin + k * pb_step;
     for (int pc = wave; pc < JT; pc += NW)
-      glds16s(a.D + (pb * JT + pc) * 64, (uint32_t)lane * 16u, rD + ((k % NB) * JT + pc) * 1024);
+      glds16s(a.D + (pb * (a.ks_total / 2) + a.ks_off / 2 + pc) * 64, (uint32_t)lane * 16u, rD + ((k % NB) * JT + pc) * 1024);   // (ks_total / 2 tiles per pixel block; wider layers: a 256-neuron slice at tile ks_off / 2)
   };
   auto convert = [&](int k) {
     const char* src = rD + (k % NB) * JT * 1024;

@@ -33,6 +33,7 @@ struct WImgArgs {
   float scale;
   int f16;
   uint16_t* dst;
+  const float* link;    // fp8 deltas: *link (a power of two, k_fp8_links) multiplies the scale; nullptr: 1
 };
 __global__ void k_wimage(WImgArgs a) {
   const long total = (long)a.n_ob * a.n_chunk * a.OT * 4 * 512;
@@ -49,7 +50,8 @@ __global__ void k_wimage(WImgArgs a) {
   const int mrow = (ob * a.OT + ot) * 32 + r, mk = 16 * (4 * c + s4) + pi_perm(h, j);
   const int mrows = a.transpose ? a.cols : a.rows, mcols = a.transpose ? a.rows : a.cols;
   float v = 0.f;
-  if (mrow < mrows && mk < mcols) v = (a.transpose ? a.W[(long)mk * a.cols + mrow] : a.W[(long)mrow * a.cols + mk]) * a.scale;
+  const float sc = a.scale * (a.link ? a.link[0] : 1.0f);      // (one factor: a single rounding into the 16-bit image)
+  if (mrow < mrows && mk < mcols) v = (a.transpose ? a.W[(long)mk * a.cols + mrow] : a.W[(long)mrow * a.cols + mk]) * sc;
   a.dst[gid] = a.f16 ? to_f16(v) : to_bf16(v);
 }
 
@@ -139,6 +141,7 @@ struct WGemmArgs {
   int ks_out;
   int kp_out;            // P8: phase-byte pieces per pixel block (= width / 32) of Out (MODE 0) / Pprev (MODE 2)
   const u32x4* Pprev;    // MODE 2: phases of the layer whose delta is produced (same geometry as Out)
+  const float* fscale;   // MODE 2, fp8 out: *fscale multiplies the outgoing deltas (the chunk factor, last layer's launch); nullptr: 1
   // MODE 1 (last layer)
   const float* img; float* pred; float gscale; float* sse_part; u32x4* Dlast; long pix0, npix;
   int nout;              // out_features (1..3): channel count and stride of img / pred
@@ -284,14 +287,18 @@ __global__ __launch_bounds__(512) void k_wgemm(WGemmArgs a) {
 // of three - so that TWO workgroups share a CU (2 x 72 KiB of LDS, 2 waves per SIMD as before): they drift apart, and the
 // epilogue of one (128 sines per thread, matrix pipe idle) runs beside the main loop of the other.  a.n_super then counts
 // 128-pixel units.
-template <int MODE, typename OP, bool P8 = false, int NWV = 8>
+// IN8 / OUT8 (MODE 2, scratch_format 8 on the wide path, round 3): the incoming / outgoing deltas are fp8 e4m3 byte pieces, one
+// per (pixel block, 32-neuron tile) in the phase-byte layout: a B chunk of two k-steps is ONE piece per pixel block (converted
+// in registers, exact), a tile's sixteen outgoing values leave in one store.  Scales: csrc/siren_kernels.hip k_fp8_links.
+template <int MODE, typename OP, bool P8 = false, int NWV = 8, bool IN8 = false, bool OUT8 = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs a) {
   static_assert(MODE == 0 || MODE == 2, "last layer: k_wgemm<1>");
   static_assert(NWV == 8 || NWV == 4, "waves per workgroup");
+  static_assert(MODE == 2 || (!IN8 && !OUT8), "fp8 deltas: the data-gradient product only");
   constexpr int OT = 8, TW = 4, PBW = 2, NPB = NWV;              // pixel blocks per workgroup: two per wave pair
   constexpr int NB = NWV == 8 ? 4 : 3, PD = NB - 1, SLOT = (16 + 2 * NPB) * 1024;
-  constexpr int GA = 16 / NWV, GB = 2 * NPB / NWV, G = GA + GB;   // LDS-DMA instructions per wave and chunk
-  constexpr int NEP = MODE == 0 ? TW * PBW * (P8 ? 3 : 4) : TW * PBW * 2;   // epilogue stores per wave (phase + activation / delta)
+  constexpr int GA = 16 / NWV, GB = (IN8 ? NPB : 2 * NPB) / NWV, G = GA + GB;   // LDS-DMA instructions per wave and chunk
+  constexpr int NEP = MODE == 0 ? TW * PBW * (P8 ? 3 : 4) : TW * PBW * (OUT8 ? 1 : 2);   // epilogue stores per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -319,8 +326,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const int pc = wave + NWV * i, p = pc >> 1, s2 = pc & 1;
-      glds16s(a.Bin + ((pbg + p) * a.ks_in + 2 * c + s2) * 64, (uint32_t)lane * 16u, base + (16 + pc) * 1024);
+      const int pc = wave + NWV * i;
+      if constexpr (IN8) {      // byte piece c of pixel block pc: k-steps 2 c, 2 c + 1
+        glds16s(a.Bin + ((pbg + pc) * (a.ks_in / 2) + c) * 64, (uint32_t)lane * 16u, base + (16 + pc) * 1024);
+      } else {
+        const int p = pc >> 1, s2 = pc & 1;
+        glds16s(a.Bin + ((pbg + p) * a.ks_in + 2 * c + s2) * 64, (uint32_t)lane * 16u, base + (16 + pc) * 1024);
+      }
     }
   };
   f32x16 init[TW];
@@ -372,11 +384,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
       }
       const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
       const u32x4* sB = sA + 16 * 64;
+      u32x4 braw[PBW];
+      if constexpr (IN8) {
+#pragma unroll
+        for (int p = 0; p < PBW; ++p) braw[p] = sB[(pw + p) * 64];
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         u32x4 b[PBW];
 #pragma unroll
-        for (int p = 0; p < PBW; ++p) b[p] = sB[((pw + p) * 2 + s2) * 64];
+        for (int p = 0; p < PBW; ++p) {
+          if constexpr (IN8) b[p] = s2 == 0 ? fp8x8_to_f16(braw[p].x, braw[p].y) : fp8x8_to_f16(braw[p].z, braw[p].w);
+          else b[p] = sB[((pw + p) * 2 + s2) * 64];
+        }
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
           const u32x4 fa = sA[((t0 + t) * 2 + s2) * 64];
@@ -422,30 +442,48 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
           if constexpr (P8) a.Out[((pb0 + p) * a.kp_out + 8 * ob + (t0 + t)) * 64 + lane] = u32x4{pb8[0], pb8[1], pb8[2], pb8[3]};
         }
     } else {
+      float fsc = 1.0f;
+      if constexpr (OUT8) fsc = a.fscale ? a.fscale[0] : 1.0f;
 #pragma unroll
       for (int t = 0; t < TW; ++t)
 #pragma unroll
-        for (int p = 0; p < PBW; ++p)
+        for (int p = 0; p < PBW; ++p) {
+          uint32_t o8[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
             const long pidx = ((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane;
-            u32x4 o;
+            float c[8];
             if constexpr (P8) {
               const u32x4 pvv = pv[t][p][0];
               const uint32_t w0 = pvv[2 * qq], w1 = pvv[2 * qq + 1];     // bytes 8 qq .. 8 qq + 7
-              o[0] = OP::pack2(acc[t][p][8 * qq + 0] * __builtin_amdgcn_cosf(phase_rev8<0>(w0)), acc[t][p][8 * qq + 1] * __builtin_amdgcn_cosf(phase_rev8<1>(w0)));
-              o[1] = OP::pack2(acc[t][p][8 * qq + 2] * __builtin_amdgcn_cosf(phase_rev8<2>(w0)), acc[t][p][8 * qq + 3] * __builtin_amdgcn_cosf(phase_rev8<3>(w0)));
-              o[2] = OP::pack2(acc[t][p][8 * qq + 4] * __builtin_amdgcn_cosf(phase_rev8<0>(w1)), acc[t][p][8 * qq + 5] * __builtin_amdgcn_cosf(phase_rev8<1>(w1)));
-              o[3] = OP::pack2(acc[t][p][8 * qq + 6] * __builtin_amdgcn_cosf(phase_rev8<2>(w1)), acc[t][p][8 * qq + 7] * __builtin_amdgcn_cosf(phase_rev8<3>(w1)));
+              c[0] = __builtin_amdgcn_cosf(phase_rev8<0>(w0)); c[1] = __builtin_amdgcn_cosf(phase_rev8<1>(w0));
+              c[2] = __builtin_amdgcn_cosf(phase_rev8<2>(w0)); c[3] = __builtin_amdgcn_cosf(phase_rev8<3>(w0));
+              c[4] = __builtin_amdgcn_cosf(phase_rev8<0>(w1)); c[5] = __builtin_amdgcn_cosf(phase_rev8<1>(w1));
+              c[6] = __builtin_amdgcn_cosf(phase_rev8<2>(w1)); c[7] = __builtin_amdgcn_cosf(phase_rev8<3>(w1));
             } else {
               const u32x4 pvv = pv[t][p][qq];
 #pragma unroll
-              for (int j2 = 0; j2 < 4; ++j2)
-                o[j2] = OP::pack2(acc[t][p][8 * qq + 2 * j2] * __builtin_amdgcn_cosf(phase_rev_lo(pvv[j2])),
-                                  acc[t][p][8 * qq + 2 * j2 + 1] * __builtin_amdgcn_cosf(phase_rev_hi(pvv[j2])));
+              for (int j2 = 0; j2 < 4; ++j2) {
+                c[2 * j2] = __builtin_amdgcn_cosf(phase_rev_lo(pvv[j2]));
+                c[2 * j2 + 1] = __builtin_amdgcn_cosf(phase_rev_hi(pvv[j2]));
+              }
             }
-            a.Out[pidx] = o;
+            if constexpr (OUT8) {
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = acc[t][p][8 * qq + j] * (c[j] * fsc);
+              o8[2 * qq] = fp8x4_sat(v[0], v[1], v[2], v[3]);
+              o8[2 * qq + 1] = fp8x4_sat(v[4], v[5], v[6], v[7]);
+            } else {
+              u32x4 o;
+#pragma unroll
+              for (int j2 = 0; j2 < 4; ++j2)
+                o[j2] = OP::pack2(acc[t][p][8 * qq + 2 * j2] * c[2 * j2], acc[t][p][8 * qq + 2 * j2 + 1] * c[2 * j2 + 1]);
+              a.Out[pidx] = o;
+            }
           }
+          if constexpr (OUT8) a.Out[((pb0 + p) * a.kp_out + 8 * ob + (t0 + t)) * 64 + lane] = u32x4{o8[0], o8[1], o8[2], o8[3]};
+        }
     }
     if (!more) break;
     if (!pipe) {
@@ -469,11 +507,15 @@ struct WDwArgs {
   float* slab;                              // [gridDim.y][gridDim.x][JW*256 + JW]
 };
 
-template <int JW, typename OP>
+// D8 (scratch_format 8 on the wide path): the deltas arrive as fp8 byte pieces (a.ksd_total then counts 32-neuron TILES per pixel
+// block); a delta^T fragment is one ds_read_b64_tr_b8 + four conversions, its rows come out permuted by nu8 (undone when the slab
+// is written) - the operand path of k_bwd8h (siren_s8h.hip), whose lane maps are used here.
+template <int JW, typename OP, bool D8 = false>
 __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
+  static_assert(!D8 || JW == 256, "byte deltas: hidden layers");
   constexpr int WAVES_R = JW == 256 ? 2 : 1, WAVES_C = 8 / WAVES_R, NW = 8;
   constexpr int JT = JW / 32, IT = 8, WJ = JT / WAVES_R, WI = IT / WAVES_C;
-  constexpr int KSJ = JW / 16, KSI = 16, NB = 4, PD = 3, BLK = (KSJ + KSI) * 1024;
+  constexpr int KSJ = D8 ? JW / 32 : JW / 16, KSI = 16, NB = 4, PD = 3, BLK = (KSJ + KSI) * 1024;   // (KSJ: delta pieces per block)
   constexpr int G = KSJ % NW == 0 ? KSJ / NW + KSI / NW : 0;   // LDS-DMA instructions per wave per block (0: uneven)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -484,7 +526,11 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
   // (of different column blocks) at the same time and sit on the same XCD (gridDim.x is a multiple of 8), so
   // each delta / phase piece is pulled from HBM once and served to the other readers by that XCD's L2
   const int jb = blockIdx.y / a.nblk_i, ib = blockIdx.y % a.nblk_i;
-  const int ksd_off = 16 * jb, ksp_off = 16 * ib;
+  const int ksd_off = (D8 ? 8 : 16) * jb, ksp_off = 16 * ib;
+  // byte pieces: LDS slot i holds the element of lane i ^ 8 (i >> 5); transposed byte reads: see k_bwd8h
+  const uint32_t aL8 = (uint32_t)(lane ^ ((lane >> 5) << 3)) * 16u;
+  const uint32_t aT8 = 16u * (32u * (uint32_t)(lane & 1) + ((8u * (uint32_t)(lane >> 5) + (uint32_t)((lane & 15) >> 1)) ^ (8u * (uint32_t)(lane & 1)))) +
+                       8u * (uint32_t)((lane >> 4) & 1);
   const long pb_begin = blockIdx.x, pb_step = gridDim.x;
   const int nblk = (int)((a.n_pb - pb_begin + pb_step - 1) / pb_step);
   f32x16 acc[WJ][WI];
@@ -499,9 +545,15 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
     char* base = smem + (k % NB) * BLK;
     const long pb = pb_begin + k * pb_step;
     for (int pc = wave; pc < KSJ; pc += NW)
-      glds16s(a.D + (pb * a.ksd_total + ksd_off + pc) * 64, (uint32_t)sw_lane(lane, pc & 1) * 16u, base + pc * 1024);
+      glds16s(a.D + (pb * a.ksd_total + ksd_off + pc) * 64, D8 ? aL8 : (uint32_t)sw_lane(lane, pc & 1) * 16u, base + pc * 1024);
     for (int pc = wave; pc < KSI; pc += NW)
       glds16s(a.P + (pb * a.ksp_total + ksp_off + pc) * 64, (uint32_t)sw_lane(lane, pc & 1) * 16u, base + (KSJ + pc) * 1024);
+  };
+  auto d8_frag = [&](const char* sD, int tile, int kk) -> u32x4 {
+    typedef __attribute__((ext_vector_type(2))) int i32x2;
+    const uint32_t adr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)sD + aT8 + (uint32_t)(tile * 1024 + kk * 256);
+    const i32x2 r = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(uintptr_t)adr);
+    return fp8x8_to_f16((uint32_t)r.x, (uint32_t)r.y);
   };
   for (int k = 0; k < PD && k < nblk; ++k) stage(k);
 #ifdef SF_EXPERIMENT_STAMP   // timing-only build: where one wave's block step goes (wait / DMA issue / compute)
@@ -520,11 +572,11 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
     char* nbase = smem + ((k + PD) % NB) * BLK;
     const long npb = pb_begin + (long)(k + PD) * pb_step;
     auto stage_piece = [&](int i) {     // i-th of this wave's G pieces of block k+PD
-      if (!do_stage) return;
-      constexpr int GD = KSJ / NW;      // delta pieces per wave
+      if (!do_stage || i >= G) return;
+      constexpr int GD = KSJ / NW;      // delta pieces per wave (D8: one)
       if (i < GD) {
         const int pc = wave + NW * i;
-        glds16s(a.D + (npb * a.ksd_total + ksd_off + pc) * 64, (uint32_t)sw_lane(lane, pc & 1) * 16u, nbase + pc * 1024);
+        glds16s(a.D + (npb * a.ksd_total + ksd_off + pc) * 64, D8 ? aL8 : (uint32_t)sw_lane(lane, pc & 1) * 16u, nbase + pc * 1024);
       } else {
         const int pc = wave + NW * (i - GD);
         glds16s(a.P + (npb * a.ksp_total + ksp_off + pc) * 64, (uint32_t)sw_lane(lane, pc & 1) * 16u, nbase + (KSJ + pc) * 1024);
@@ -539,7 +591,7 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
     for (int kk = 0; kk < 2; ++kk) {
       u32x4 fa[WJ], fb[WI];
 #pragma unroll
-      for (int x = 0; x < WJ; ++x) fa[x] = ds_read_tr_frag(sD, trb, wr * WJ + x, kk);
+      for (int x = 0; x < WJ; ++x) fa[x] = D8 ? d8_frag(sD, wr * WJ + x, kk) : ds_read_tr_frag(sD, trb, wr * WJ + x, kk);
 #pragma unroll
       for (int y = 0; y < WI; ++y) fb[y] = ds_read_tr_frag(sP, trb, wc * WI + y, kk);
 #pragma unroll
@@ -582,13 +634,33 @@ __global__ __launch_bounds__(512) void k_wdw(WDwArgs a) {
     for (int y = 0; y < WI; ++y)
 #pragma unroll
       for (int t = 0; t < 16; ++t)
-        slab[(size_t)(32 * (wr * WJ + x) + rho(t, hh)) * 256 + 32 * (wc * WI + y) + cl] = acc[x][y][t];
+        slab[(size_t)(32 * (wr * WJ + x) + (D8 ? nu8(rho(t, hh)) : rho(t, hh))) * 256 + 32 * (wc * WI + y) + cl] = acc[x][y][t];
   if (wc == 0) {
 #pragma unroll
     for (int x = 0; x < WJ; ++x) {
       const float tsum = dbs[x] + __shfl_xor(dbs[x], 32);
-      if (hh == 0) slab[JW * 256 + 32 * (wr * WJ + x) + cl] = tsum;
+      if (hh == 0) slab[JW * 256 + 32 * (wr * WJ + x) + (D8 ? nu8(cl) : cl)] = tsum;
     }
+  }
+}
+
+// fp8 deltas on the wide path: the chunk's power-of-two factor from its residual.  dL/dout is stored as resid * pre (pre = the
+// 16-bit path's static gscale); F = 2^floor(log2(target / (rms(resid) * pre))) brings the first hidden delta to the target rms (its
+// own gain is normalised by the last layer's link).  One workgroup, partials summed in double in fixed order; out[0] = F, out[1] = 1 / (F * gpre).
+__global__ __launch_bounds__(256) void k_wchunk_scale(const float* sse_part, int n_part, double inv_values, float pre, float gpre, float target, float* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n_part; i += 256) s += (double)sse_part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 256; ++i) t += sh[i];
+    double rms = sqrt(t * inv_values);
+    if (!(rms > 1e-12)) rms = 1e-12;
+    if (rms > 4.0) rms = 4.0;
+    const double F = exp2(floor(log2((double)target / (rms * (double)pre))));
+    out[0] = (float)F; out[1] = (float)(1.0 / (F * (double)gpre));     // [1]: what a weight gradient formed from these deltas is multiplied by
   }
 }
 
@@ -600,8 +672,10 @@ struct WReduceArgs {
   float* gW; int ldw;                           // gradient matrix [rows][ldw]; block (jb, ib) starts at [256 jb][256 ib]
   float* gb;                                    // bias gradient (taken from the ib == 0 blocks)
   int accumulate; float scale;
+  const float* s1; const float* s2;             // fp8 deltas: s1[1] = 1 / (chunk factor * gpre) REPLACES scale, s2[0] = 1 / cumulative layer scale
 };
 __global__ void k_wreduce(WReduceArgs a) {
+  const float mul = (a.s1 ? a.s1[1] : a.scale) * (a.s2 ? a.s2[0] : 1.0f);      // (powers of two: exact)
   const long slab_sz = (long)a.slab_rows * 256 + a.slab_rows;
   const int jb = blockIdx.y / a.nblk_i, ib = blockIdx.y % a.nblk_i;
   const float* slab = a.slab + (size_t)blockIdx.y * a.n_wg * slab_sz;
@@ -613,7 +687,7 @@ __global__ void k_wreduce(WReduceArgs a) {
     const float* p = slab + (long)j * 256 + i;
     float s = 0.f;
     for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz];
-    s *= a.scale;
+    s *= mul;
     float* o = a.gW + (long)(256 * jb + j) * a.ldw + 256 * ib + i;
     *o = a.accumulate ? *o + s : s;
   } else {
@@ -621,7 +695,7 @@ __global__ void k_wreduce(WReduceArgs a) {
     const float* p = slab + (long)a.slab_rows * 256 + j;
     float s = 0.f;
     for (int w = 0; w < a.n_wg; ++w) s += p[w * slab_sz];
-    s *= a.scale;
+    s *= mul;
     float* o = a.gb + 256 * jb + j;
     *o = a.accumulate ? *o + s : s;
   }

@@ -369,8 +369,58 @@ def test_wide_phase_bytes_psnr_parity_and_auto_rule():
     big.set_masks(torch.ones(2 * 512 + 512 + 512 * 512 + 512 + 512 * 3 + 3, device="cuda"))
     assert big.scratch_format == 16
     big.close()
-    with pytest.raises(RuntimeError):
-        SirenEngine(64, 64, 512, 3, scratch_format=8)
+    e8 = SirenEngine(64, 64, 512, 3, scratch_format=8)          # fp8 deltas on the wide path: explicit only
+    assert e8.scratch_format == 8
+    e8.close()
+
+
+@pytest.mark.parametrize("H,W,hidden,depth,chunk,tol", [(40, 52, 512, 5, 0, 6e-2), (48, 48, 1024, 4, 1024, 5e-2), (24, 40, 512, 8, 0, 1e-1),
+                                                         (128, 128, 512, 6, 0, 2.5e-2)])
+def test_wide_fp8_deltas_gradients(H, W, hidden, depth, chunk, tol):
+    """Format 8 on the layer-at-a-time kernels (k_wgemm2<2, .., IN8 / OUT8>, k_wdw<256, .., D8>, k_dw0_8 per 256-neuron slice):
+    the deltas between the layers' backward kernels are fp8 e4m3 byte pieces under the chunk factor (k_wchunk_scale) and the
+    per-layer links of the width-256 path (k_fp8_links, folded into the backward images by k_wimage).  Every gradient tensor
+    stays within the fp8 rounding noise of the fp32 oracle - zero-mean 2^-4 per delta, summed over the pixels: measured
+    6e-2 (960 pixels) ... 1.2e-2 (16 384 pixels) for the worst tensor, about 4x format 12 - and finite; the last layer's
+    gradient (16-bit dL/dout) is format 12's bit for bit; ragged and multi-chunk grids included."""
+    p = so.siren_init(hidden, depth, seed=3)
+    img = so.synthetic_image(H, W, seed=5)
+    e12 = _engine(H, W, hidden, depth, "f16", p, img, chunk_pixels=chunk, scratch_format=12)
+    e8 = _engine(H, W, hidden, depth, "f16", p, img, chunk_pixels=chunk, scratch_format=8)
+    _, _, grads = so.loss_and_grads(p, so.get_grid(H, W), img)
+    ref = so.flatten(grads)
+    e12.forward_backward(); e8.forward_backward()
+    g12, g8 = e12.get_grads().cpu().numpy(), e8.get_grads().cpu().numpy()
+    assert np.isfinite(g8).all()
+    off = 0
+    for fin, fout in so.layer_dims(hidden, depth):
+        for n in (fin * fout, fout):
+            a, b = g8[off:off + n], ref[off:off + n]
+            off += n
+            assert np.linalg.norm(a - b) <= tol * np.linalg.norm(b) + 1e-12, (fin, fout, n)
+    n_last = hidden * 3 + 3
+    assert np.array_equal(g8[-n_last:], g12[-n_last:])
+    # a second pass reproduces the first (fixed-order sums, stateless scales)
+    e8.forward_backward()
+    assert np.array_equal(e8.get_grads().cpu().numpy(), g8)
+
+
+def test_wide_fp8_deltas_psnr_parity():
+    """test_wide_psnr_parity_after_equal_steps with format 8: SIREN 512x4 on 96x96, 60 Adam steps: within 0.05 dB of the fp32
+    oracle (measured 0.005 dB)."""
+    H = W = 96
+    hidden, depth, steps = 512, 4, 60
+    img, grid = so.synthetic_image(H, W, seed=8), so.get_grid(H, W)
+    p = so.siren_init(hidden, depth, seed=0)
+    eng = _engine(H, W, hidden, depth, "f16", p, img, scratch_format=8)
+    got = np.array(eng.step([so.step_lr(3e-4, t) for t in range(steps)], want_loss=True))
+    opt = so.Adam(p)
+    ref = np.array([so.train_epoch(p, opt, grid, img, t) for t in range(steps)])
+    assert np.abs(got / ref - 1).max() <= 2e-2
+    _, sse = eng.forward(want_pred=False)
+    psnr = 10 * math.log10(3 * H * W / sse)
+    _, _, psnr_ref, _ = so.eval_epoch(p, grid, img)
+    assert abs(psnr - psnr_ref) <= 0.05, (psnr, psnr_ref)
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
