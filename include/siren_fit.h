@@ -74,9 +74,11 @@ typedef struct sf_config {
   int32_t scratch_format;   /* width of the two tensors the backward re-reads from HBM (phases, deltas):
                              * 16 = unorm16 phases + 16-bit float deltas (round-1 format);
                              * 12 = phase BYTES + 16-bit float deltas;
-                             *  8 = phase bytes + fp8 e4m3 deltas under a per-chunk adaptive power-of-two pre-scale;
-                             *  0 = auto: hidden <= 256 with SF_F16 (8 and 12 exist only there): 8 for images of >= 2^20
-                             *      pixels, 12 below; else 16.  An auto handle moves to 16 when sf_set_masks sets a mask
+                             *  8 = phase bytes + fp8 e4m3 deltas under one power-of-two scale per pixel chunk (from the
+                             *      chunk's residual) times one per layer (from the layer's weight norm);
+                             *  0 = auto, SF_F16 only (8 and 12 need fp16 operands; else 16): hidden <= 256: 8 for images of
+                             *      >= 2^20 pixels, 12 below; hidden > 256: 12 from 2^20 pixels, 16 below (8 is accepted
+                             *      there when asked for).  An auto handle moves to 16 when sf_set_masks sets a mask
                              *      (sparse networks: DESIGN.md section 2)                                             */
 } sf_config;
 
