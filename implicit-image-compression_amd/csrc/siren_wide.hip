@@ -19,6 +19,14 @@
 
 namespace sf {
 
+#ifdef SF_WEXP_NOSTORE   // timing-only: the GEMM epilogues compute their values and drop them
+#define WST(dst, val) do { auto v_ = (val); asm volatile("" ::"v"(v_)); } while (0)
+#elif defined(SF_WEXP_NTSTORE)   // A/B: non-temporal epilogue stores
+#define WST(dst, val) __builtin_nontemporal_store((val), &(dst))
+#else
+#define WST(dst, val) (dst) = (val)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // blocked A image: [ob][chunk c][tile ot][s4][lane][8] ; chunk = 4 k-steps ; OT tiles of 32 rows per block
 // element (ob, c, ot, s4, lane=(r,h), j) = M[(ob*OT + ot)*32 + r][16*(4c + s4) + PI(h, j)] * scale   (0 outside)
@@ -348,6 +356,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
     }
   }
   asm volatile("" ::"v"(init[0][0]), "v"(init[TW - 1][15]));   // bias loads retire before the first DMA is issued
+#ifdef SF_WEXP_STAGGER   // A/B: workgroups start 1/16 of a tile apart (breaks the convoy in which every CU stores at the same time)
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 15) * SF_WEXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
   for (int c = 0; c < PD && c < n2; ++c) stage(sb, c);
   bool first = true;
   while (true) {
@@ -412,6 +423,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
       for (int c = 0; c < PD; ++c) stage(sbn, c);
       asm volatile("" ::: "memory");
     }
+#ifdef SF_WEXP_NOEPI   // timing-only: no epilogue at all (the accumulators are consumed by an empty asm)
+    if (true) {
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int p = 0; p < PBW; ++p) asm volatile("" ::"v"(acc[t][p]));
+    } else
+#endif
     if (MODE == 0) {
 #pragma unroll
       for (int t = 0; t < TW; ++t)
@@ -433,13 +452,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
               pb8[2 * qq] = phase_byte4(tv, av);
               pb8[2 * qq + 1] = phase_byte4(tv + 4, av + 4);
             } else {
-              a.Out[pidx] = u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
-                                  pack_phase2(ph[6], ph[7])};
+              WST(a.Out[pidx], (u32x4{pack_phase2(ph[0], ph[1]), pack_phase2(ph[2], ph[3]), pack_phase2(ph[4], ph[5]),
+                                  pack_phase2(ph[6], ph[7])}));
             }
-            a.OutAct[pidx] = u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]),
-                                   OP::pack2(av[6], av[7])};
+            WST(a.OutAct[pidx], (u32x4{OP::pack2(av[0], av[1]), OP::pack2(av[2], av[3]), OP::pack2(av[4], av[5]),
+                                   OP::pack2(av[6], av[7])}));
           }
-          if constexpr (P8) a.Out[((pb0 + p) * a.kp_out + 8 * ob + (t0 + t)) * 64 + lane] = u32x4{pb8[0], pb8[1], pb8[2], pb8[3]};
+          if constexpr (P8) WST(a.Out[((pb0 + p) * a.kp_out + 8 * ob + (t0 + t)) * 64 + lane], (u32x4{pb8[0], pb8[1], pb8[2], pb8[3]}));
         }
     } else {
       float fsc = 1.0f;
@@ -479,10 +498,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
 #pragma unroll
               for (int j2 = 0; j2 < 4; ++j2)
                 o[j2] = OP::pack2(acc[t][p][8 * qq + 2 * j2] * c[2 * j2], acc[t][p][8 * qq + 2 * j2 + 1] * c[2 * j2 + 1]);
-              a.Out[pidx] = o;
+              WST(a.Out[pidx], (o));
             }
           }
-          if constexpr (OUT8) a.Out[((pb0 + p) * a.kp_out + 8 * ob + (t0 + t)) * 64 + lane] = u32x4{o8[0], o8[1], o8[2], o8[3]};
+          if constexpr (OUT8) WST(a.Out[((pb0 + p) * a.kp_out + 8 * ob + (t0 + t)) * 64 + lane], (u32x4{o8[0], o8[1], o8[2], o8[3]}));
         }
     }
     if (!more) break;
