@@ -357,7 +357,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
   }
   asm volatile("" ::"v"(init[0][0]), "v"(init[TW - 1][15]));   // bias loads retire before the first DMA is issued
 #ifdef SF_WEXP_STAGGER   // A/B: workgroups start 1/16 of a tile apart (breaks the convoy in which every CU stores at the same time)
-  for (int i = 0; i < (int)((blockIdx.x >> 3) & 15) * SF_WEXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+  // (workgroup q = blockIdx.x >> 3 of an XCD goes to CU q mod 32: the second workgroup of a CU is q + 32 - it gets half a tile more)
+  for (int i = 0; i < (int)((((blockIdx.x >> 3) & 15) + 8 * ((blockIdx.x >> 8) & 1)) & 15) * SF_WEXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
 #endif
   for (int c = 0; c < PD && c < n2; ++c) stage(sb, c);
   bool first = true;
@@ -374,10 +375,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
       // c+1, c+2 and - in the first PD steps of a tile that follows another - that tile's NEP epilogue stores
       // (in flight behind chunk c: min(PD - 1, n2 - 1 - c) chunks of G instructions each)
       if (!pipe) bar_all();
+#ifndef SF_WEXP_LAXWAIT
       else if (c + 1 >= n2) bar_all();
       else if (PD == 3 && c + 2 >= n2) bar_dma<G>();
+#endif
+#ifdef SF_WEXP_LAXWAIT   // timing-only (RACY): no wait ever requires the previous tile's stores to have retired
+      else bar_dma<(PD - 1) * G + NEP>();
+#else
       else if (first || c >= PD) bar_dma<(PD - 1) * G>();
       else bar_dma<(PD - 1) * G + NEP>();
+#endif
       if (c + PD < n2) stage(sb, c + PD);
       asm volatile("" ::: "memory");
       if (MODE == 2 && c == n2 - 1) {
