@@ -236,14 +236,14 @@ def test_erk_at_1024x12_reproduces_the_survey_counts():
     assert abs(float(hid.mean()) - 0.09956) < 2e-3
 
 
-@pytest.mark.parametrize("hidden,depth,H,W", [(512, 4, 24, 40), (1024, 3, 16, 33)])
-def test_masks_on_the_wide_kernels(hidden, depth, H, W):
+@pytest.mark.parametrize("hidden,depth,H,W,fmt", [(512, 4, 24, 40, 0), (1024, 3, 16, 33, 0), (512, 4, 24, 40, 12), (512, 4, 24, 40, 8)])
+def test_masks_on_the_wide_kernels(hidden, depth, H, W, fmt):
     """masks set on a 512- and a 1024-wide engine stay exactly zero through 10 steps, and the losses
     track the masked fp32 oracle (as test_masks_are_applied_inside_the_step does at width 64).  Reference:
     masking/core.py:271-279 (apply_mask), 671-702 (step)."""
     p = so.siren_init(hidden, depth, seed=0)
     img = so.synthetic_image(H, W, seed=9)
-    eng = _engine(H, W, hidden, depth, "f16", p, img)
+    eng = _engine(H, W, hidden, depth, "f16", p, img, scratch_format=fmt)     # (explicit byte formats keep their format under a mask)
     gen = torch.Generator().manual_seed(1)
     masks, flat = [], []
     for q in p:
@@ -257,10 +257,11 @@ def test_masks_on_the_wide_kernels(hidden, depth, H, W):
     grid = so.get_grid(H, W)
     ref = [so.train_epoch(p, opt, grid, img, t, masks=masks) for t in range(10)]
     got = eng.step([3e-4] * 10, want_loss=True)
-    assert np.max(np.abs(np.array(got) - np.array(ref)) / np.array(ref)) <= 3e-3, (got, ref)
+    assert eng.scratch_format == (16 if fmt == 0 else fmt)
+    assert np.max(np.abs(np.array(got) - np.array(ref)) / np.array(ref)) <= (3e-3 if fmt in (0, 16) else 2e-2), (got, ref)
     w = eng.get_params().cpu()
     assert torch.all(w[torch.cat(flat) == 0] == 0)               # bit-exact: masked weights stay zero
-    assert _rel_t(w, torch.tensor(so.flatten(p))) <= 2e-3
+    assert _rel_t(w, torch.tensor(so.flatten(p))) <= (2e-3 if fmt in (0, 16) else 2e-2)
 
 
 def _rel_t(a, b):
