@@ -613,6 +613,25 @@ int launch_wgemm(sf_engine* h, const WGemmArgs& a, int n_super, int n_ob) {
         return SF_OK;
       }
     }
+    if constexpr (MODE == 0) {
+      // k_wgemm3 (epilogue pipelined under the next tile, stores spread evenly) is correct and measured EQUAL to the tile loop below
+      // (DESIGN.md section 4b): opt-in
+      static const bool g3 = getenv("SIREN_FIT_WGEMM3") && atoi(getenv("SIREN_FIT_WGEMM3")) == 1;
+      if (g3 && f16 && h->s8 && (a.ks_in == 32 || a.ks_in == 64)) {   // forward hidden layers with the epilogue pipelined under the next tile
+        b.n_super = 2 * n_super;                            // 128-pixel units
+        b.dump = reinterpret_cast<u32x4*>(h->pad8 + 8192);
+        const size_t lds3 = (size_t)4 * 24 * 1024 + 1024;
+        const unsigned grid3 = (unsigned)((b.n_super + 7) / 8 * 8 * n_ob);
+        unsigned pg = (unsigned)(h->dw_wg / (8 * n_ob) * (8 * n_ob));
+        if (pg == 0 || pg > grid3) pg = grid3;
+        int rc = a.ks_in == 32 ? set_lds(k_wgemm3<32>, lds3) : set_lds(k_wgemm3<64>, lds3);
+        if (rc) return rc;
+        if (a.ks_in == 32) hipLaunchKernelGGL((k_wgemm3<32>), dim3(pg), dim3(512), lds3, h->stream, b);
+        else hipLaunchKernelGGL((k_wgemm3<64>), dim3(pg), dim3(512), lds3, h->stream, b);
+        HIPCHK(hipGetLastError());
+        return SF_OK;
+      }
+    }
     static const bool w4 = getenv("SIREN_FIT_WGEMM4") && atoi(getenv("SIREN_FIT_WGEMM4")) == 1;   // A/B knob: four-wave workgroups, two per CU
     if (w4 && f16 && a.ks_in >= 8) {
       b.n_super = 2 * n_super;                              // 128-pixel units

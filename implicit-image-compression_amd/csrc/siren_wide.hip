@@ -149,6 +149,7 @@ struct WGemmArgs {
   int ks_out;
   int kp_out;            // P8: phase-byte pieces per pixel block (= width / 32) of Out (MODE 0) / Pprev (MODE 2)
   const u32x4* Pprev;    // MODE 2: phases of the layer whose delta is produced (same geometry as Out)
+  u32x4* dump;           // k_wgemm3: 8 KiB the first tile's (empty) epilogue is stored to
   const float* fscale;   // MODE 2, fp8 out: *fscale multiplies the outgoing deltas (the chunk factor, last layer's launch); nullptr: 1
   // MODE 1 (last layer)
   const float* img; float* pred; float gscale; float* sse_part; u32x4* Dlast; long pix0, npix;
@@ -519,6 +520,188 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
     sb = sbn;
     first = false;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_wgemm3 (round 3): the forward hidden GEMM of k_wgemm2<0, .., P8> with its epilogue PIPELINED UNDER THE NEXT TILE.
+// An experiment that is kept because of what it rules out (opt-in: SIREN_FIT_WGEMM3=1).  Timing-only builds say the epilogue
+// stores of the wide GEMMs cost their full drain time (15 of 57 ms at 512x8, profiles/r03_wide_store_ablation.txt); the
+// suspicion was the BURST - with the epilogue at the end of a 256 x 256 tile every wave issues its 24 stores back to back,
+// whereas k_fwd_pipe and k_bwd8h, which do not pay for their stores, let them leave one at a time between MFMAs.  So here:
+//   tile = 256 neurons x 128 pixels (wave = 4 row tiles x ONE pixel block: 64 accumulator registers, two sets);
+//   the operand ring streams CONTINUOUSLY across tiles (chunk g of the workgroup's whole sequence, 24 KiB: 16 A + 8 B pieces);
+//   while tile T accumulates in one set, the other set - tile T-1 - is drained: VPK values per k-step (sine, phase byte, pack),
+//   an activation store every 8 values, a phase-byte store every 16: 12 stores spread over the tile's k-steps.
+//   Every step is the full step (k_bwd8h's rule): the first tile drains zeros into a.dump, requests beyond the last tile re-read
+//   its chunks, the last tile is drained once more at the end - so the store pattern is periodic and every vmcnt is a constant.
+// RESULT: parity-green and exactly as fast as the tile loop (forward 20.3 against 20.0 ms per step at 512x8): it is not the burst.
+// KSI = k-steps of the layer (32 at width 512, 64 at 1024).  fp16 operands, phase bytes (scratch formats 12 / 8).
+// ---------------------------------------------------------------------------------------------------------
+template <int V> struct IntC { static constexpr int value = V; };
+template <int KSI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgemm3(WGemmArgs a) {   // (two waves per SIMD, 256 VGPRs: left to itself hipcc spills the drained accumulator set to reach three)
+  typedef OpF16 OP;
+  constexpr int OT = 8, TW = 4, NPB = 4, NB = 4, PD = 3, SLOT = 24 * 1024, N2 = KSI / 2;
+  constexpr int G = 3;                                   // LDS-DMA instructions per wave and chunk: 24 pieces / 8 waves
+  constexpr int VPK = 64 / KSI;                          // epilogue values per k-step (2 at width 512, 1 at 1024)
+  static_assert(KSI == 32 || KSI == 64, "widths 512 / 1024");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sBias = reinterpret_cast<float*>(smem + NB * SLOT);      // this output block's 256 biases
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int ob = q0 % a.n_ob;
+  const int sb_step = (gridDim.x >> 3) / a.n_ob * 8;
+  const int sb0 = (q0 / a.n_ob) * 8 + xcd;               // first 128-pixel unit of this workgroup
+  if (sb0 >= a.n_super) return;
+  const int n_tiles = (a.n_super - sb0 + sb_step - 1) / sb_step;
+  const int t0 = TW * (wave & 1), pbw = wave >> 1;
+  const u32x4* Ablk = a.A + (size_t)ob * a.a_block_pieces * 64;
+  if (tid < 256) sBias[tid] = a.bias[ob * 256 + tid];
+  // chunk g of the workgroup's sequence = chunk g % N2 of tile g / N2 (beyond the last tile: the last tile again)
+  auto stage = [&](int ti, int c, int slot) {
+    if (ti >= n_tiles) ti = n_tiles - 1;
+    char* base = smem + slot * SLOT;
+    const long pbg = (long)(sb0 + ti * sb_step) * NPB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = wave + 8 * i, ot = pc >> 1, s2 = pc & 1;
+      glds16s(Ablk + ((size_t)((c >> 1) * OT + ot) * 4 + 2 * (c & 1) + s2) * 64, (uint32_t)lane * 16u, base + pc * 1024);
+    }
+    glds16s(a.Bin + ((pbg + (wave >> 1)) * KSI + 2 * c + (wave & 1)) * 64, (uint32_t)lane * 16u, base + (16 + wave) * 1024);
+  };
+  f32x16 accA[TW], accB[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t) { accA[t] = f32x16{}; accB[t] = f32x16{}; }
+  static_assert(N2 % NB == 0 && PD < N2, "ring slots are compile-time inside a tile");
+  for (int c = 0; c < PD; ++c) stage(0, c, c);
+  // the counted waits below assume the store pattern of a tile BEFORE the first one: with the first three chunks (and the bias
+  // table) landed here they hold from step 0 (the later chunks of tile 0 are requested behind real - dumped - stores)
+  bar_all();
+  u32x4* const dumpw = a.dump + wave * 64 + lane;
+  // epilogue value v (tile v >> 4, register v & 15) of accumulator set `prv`: sine -> 16-bit pair, phase byte; an activation
+  // piece leaves after every 8 values, the tile's phase piece after 16.  (The running state is plain scalars selected by
+  // switches on what are constants after unrolling: a struct with arrays here ended up in scratch memory, with a vmcnt(0)
+  // in front of every reload.)
+  float e_av = 0.f;
+  uint32_t e_a0 = 0u, e_a1 = 0u, e_a2 = 0u, e_a3 = 0u, e_p0 = 0u, e_p1 = 0u, e_p2 = 0u, e_p3 = 0u;
+  auto put_byte = [&](uint32_t& w, int byte, float tt, float sv) __attribute__((always_inline)) {
+    switch (byte) {
+      case 0: phase_byte<0>(w, tt, sv); break;
+      case 1: phase_byte<1>(w, tt, sv); break;
+      case 2: phase_byte<2>(w, tt, sv); break;
+      default: phase_byte<3>(w, tt, sv); break;
+    }
+  };
+  auto epi_value = [&](const f32x16 (&prv)[TW], int v, long pbp, bool to_dump) __attribute__((always_inline)) {
+    const int t = v >> 4, e = v & 15;
+    const float tt = prv[t][e];
+    const float sv = __builtin_amdgcn_sinf(tt);
+    switch (e >> 2) {
+      case 0: put_byte(e_p0, e & 3, tt, sv); break;
+      case 1: put_byte(e_p1, e & 3, tt, sv); break;
+      case 2: put_byte(e_p2, e & 3, tt, sv); break;
+      default: put_byte(e_p3, e & 3, tt, sv); break;
+    }
+    if (e & 1) {
+      const uint32_t w = OP::pack2(e_av, sv);
+      switch ((e & 7) >> 1) {
+        case 0: e_a0 = w; break;
+        case 1: e_a1 = w; break;
+        case 2: e_a2 = w; break;
+        default: e_a3 = w; break;
+      }
+    } else {
+      e_av = sv;
+    }
+    if ((e & 7) == 7) {
+      u32x4* dst = to_dump ? dumpw : a.OutAct + ((pbp * KSI + 16 * ob + 2 * (t0 + t) + (e >> 3)) * 64 + lane);
+      *dst = u32x4{e_a0, e_a1, e_a2, e_a3};
+    }
+    if (e == 15) {
+      u32x4* dst = to_dump ? dumpw : a.Out + ((pbp * (KSI / 2) + 8 * ob + (t0 + t)) * 64 + lane);
+      *dst = u32x4{e_p0, e_p1, e_p2, e_p3};
+    }
+  };
+  // stores issued in chunk-step c of a tile (c taken modulo the tile: the pattern is the same in every tile)
+  auto stores_in = [](int c) constexpr -> int {
+    const int cc = ((c % N2) + N2) % N2;
+    int n = 0;
+    for (int s2 = 0; s2 < 2; ++s2)
+      for (int u = 0; u < VPK; ++u) {
+        const int e = (((2 * cc + s2) * VPK + u) & 15);
+        n += ((e & 7) == 7) + (e == 15);
+      }
+    return n;
+  };
+  // one tile: `cur` accumulates (its bias first), `prv` - the tile before - is drained into pixel block pbp (or the dump).
+  // The chunk loop is unrolled sixteen chunks at a time through a compile-time part index (a 32-chunk body is not unrolled
+  // by hipcc, and an accumulator register indexed at run time goes to scratch memory).
+  auto tile_part = [&](auto part_tag, f32x16 (&cur)[TW], const f32x16 (&prv)[TW], int ti, long pbp, bool to_dump) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part_tag)::value;
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) {
+      constexpr int dummy = 0; (void)dummy;
+      const int c = 16 * PART + ci;
+      // chunk c landed: younger than its DMA are the DMA of the next PD - 1 chunks and the stores of the last PD steps
+      const int nst = stores_in(c - 3) + stores_in(c - 2) + stores_in(c - 1);
+      switch (nst) {                                     // (a constant per c after unrolling)
+        case 0: bar_dma<(PD - 1) * G + 0>(); break;
+        case 1: bar_dma<(PD - 1) * G + 1>(); break;
+        case 2: bar_dma<(PD - 1) * G + 2>(); break;
+        case 3: bar_dma<(PD - 1) * G + 3>(); break;
+        case 4: bar_dma<(PD - 1) * G + 4>(); break;
+        case 5: bar_dma<(PD - 1) * G + 5>(); break;
+        default: bar_dma<(PD - 1) * G + 6>(); break;
+      }
+      if (c + PD < N2) stage(ti, c + PD, (c + PD) % NB); else stage(ti + 1, c + PD - N2, (c + PD) % NB);
+      asm volatile("" ::: "memory");
+      const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
+      const u32x4* sB = sA + 16 * 64;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const u32x4 b = sB[(pbw * 2 + s2) * 64];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) cur[t] = OP::mfma(sA[((t0 + t) * 2 + s2) * 64], b, cur[t]);
+#pragma unroll
+        for (int u = 0; u < VPK; ++u) epi_value(prv, (2 * c + s2) * VPK + u, pbp, to_dump);
+      }
+    }
+  };
+  auto tile = [&](f32x16 (&cur)[TW], const f32x16 (&prv)[TW], int ti, long pbp, bool to_dump) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&sBias[(t0 + t) * 32 + 8 * q4 + 4 * h]);
+        cur[t][4 * q4 + 0] = b.x; cur[t][4 * q4 + 1] = b.y; cur[t][4 * q4 + 2] = b.z; cur[t][4 * q4 + 3] = b.w;
+      }
+    tile_part(IntC<0>{}, cur, prv, ti, pbp, to_dump);
+    if constexpr (N2 > 16) tile_part(IntC<1>{}, cur, prv, ti, pbp, to_dump);
+  };
+  // tiles alternate between the two accumulator sets
+  long pb_prev = 0;
+  int ti = 0;
+  for (; ti + 1 < n_tiles; ti += 2) {
+    tile(accA, accB, ti, pb_prev, ti == 0);
+    pb_prev = (long)(sb0 + ti * sb_step) * NPB + pbw;
+    tile(accB, accA, ti + 1, pb_prev, false);
+    pb_prev = (long)(sb0 + (ti + 1) * sb_step) * NPB + pbw;
+  }
+  const bool odd = ti < n_tiles;
+  if (odd) {
+    tile(accA, accB, ti, pb_prev, ti == 0);
+    pb_prev = (long)(sb0 + ti * sb_step) * NPB + pbw;
+  }
+  // drain the last tile (a burst, once per workgroup)
+  auto drain = [&](const f32x16 (&prv)[TW]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) epi_value(prv, 16 * t + e, pb_prev, false);
+  };
+  if (odd) drain(accA); else drain(accB);
+  bar_all();      // no LDS-DMA of this workgroup is in flight when its LDS is handed on
 }
 
 // ---------------------------------------------------------------------------------------------------------
