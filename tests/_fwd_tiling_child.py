@@ -1,5 +1,6 @@
-"""Child of tests/test_gpu_fwd_tilings.py: one forward + forward_backward of SIREN 256x8 (phase-byte scratch) on a ragged
-image, with the forward tiling chosen by SIREN_FIT_FWD16 (read once per process by the library).  Writes an npz."""
+"""Child of tests/test_gpu_fwd_tilings.py: one forward + forward_backward + 20 steps of a SIREN (256x8 unless given) on a ragged
+image, with the forward kernel chosen by an environment knob the library reads once per process (SIREN_FIT_FWD16,
+SIREN_FIT_WGEMM3).  Writes an npz."""
 import os
 import sys
 
@@ -13,10 +14,11 @@ import torch  # noqa: E402
 
 def main():
     out, H, W, fmt = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    hidden, depth = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (256, 8)
     from implicit_image._engine import SirenEngine
     from oracle import siren_oracle as so           # (test infrastructure: the seed-0 init and the image formula)
-    p = so.siren_init(256, 8, seed=0)
-    eng = SirenEngine(H, W, 256, 8, compute_dtype="f16", scratch_format=fmt)
+    p = so.siren_init(hidden, depth, seed=0)
+    eng = SirenEngine(H, W, hidden, depth, compute_dtype="f16", scratch_format=fmt)
     gh, gw = so.grid_vectors(H, W)
     eng.set_coords(gh.cuda(), gw.cuda())
     eng.set_params(torch.tensor(so.flatten(p)).cuda())

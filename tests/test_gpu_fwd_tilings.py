@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, knob, H, W, fmt):
+def _run(tmp_path, knob, H, W, fmt, var="SIREN_FIT_FWD16", net=()):
     out = tmp_path / f"t{knob}.npz"
     child = os.path.join(ROOT, "tests", "_fwd_tiling_child.py")
-    r = subprocess.run([sys.executable, child, str(out), str(H), str(W), str(fmt)], env=dict(os.environ, SIREN_FIT_FWD16=str(knob)),
+    r = subprocess.run([sys.executable, child, str(out), str(H), str(W), str(fmt)] + [str(x) for x in net], env=dict(os.environ, **{var: str(knob)}),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()
     return np.load(out)
@@ -41,3 +41,14 @@ def test_forward_16x16x32_agrees_with_32x32x16(tmp_path, fmt):
     assert np.abs(a["grads"] - b["grads"]).max() <= 1e-2 * np.abs(a["grads"]).max()
     rel = np.abs(a["losses"] - b["losses"]) / a["losses"]
     assert rel[:5].max() <= 1e-2     # (measured <= 7e-3; the fast descent then amplifies the byte flips: 3 % / 13 % apart after 20 steps)
+
+
+@pytest.mark.parametrize("hidden,depth,H,W", [(512, 4, 75, 53), (1024, 3, 40, 33)])
+def test_wide_forward_with_pipelined_epilogue_is_bit_identical(tmp_path, hidden, depth, H, W):
+    """k_wgemm3 (SIREN_FIT_WGEMM3=1: the wide forward GEMM on 256 x 128 tiles, the previous tile drained under the current one)
+    sums the same products in the same order as k_wgemm2<0>: predictions, phase bytes, gradients and twenty steps of losses are
+    IDENTICAL, ragged grids included (the 128-pixel units of the last super-block, the dump of the first tile, the final drain)."""
+    a = _run(tmp_path, 0, H, W, 12, "SIREN_FIT_WGEMM3", (hidden, depth))
+    b = _run(tmp_path, 1, H, W, 12, "SIREN_FIT_WGEMM3", (hidden, depth))
+    for key in ("pred", "phases", "grads", "losses"):
+        assert np.array_equal(a[key], b[key]), key
