@@ -652,6 +652,9 @@ int launch_wgemm(sf_engine* h, const WGemmArgs& a, int n_super, int n_ob) {
       HIPCHK(hipGetLastError());
       return SF_OK;
     }
+#ifdef SF_WEXP_STAMP
+    b.dump = reinterpret_cast<u32x4*>(h->pad8 + 8192);
+#endif
     const size_t lds = (size_t)4 * 32 * 1024;
     const bool p8 = h->s8 && (MODE == 0 || b.Pprev);        // phase bytes (format 12; fp16 only: sf_create)
     int rc = p8 ? set_lds(k_wgemm2<MODE, OpF16, true>, lds) : f16 ? set_lds(k_wgemm2<MODE, OpF16>, lds) : set_lds(k_wgemm2<MODE, OpBF16>, lds);
@@ -1190,6 +1193,17 @@ int sf_destroy(sf_handle* h) try {
   if (!h) return SF_OK;
   DevGuard dev_guard(h->cfg.device);
   if (h->stream || true) hipStreamSynchronize(h->stream);
+#ifdef SF_WEXP_STAMP
+  if (h->wide) {
+    float dbg[64];
+    hipMemcpy(dbg, h->pad8 + 8192, sizeof(dbg), hipMemcpyDeviceToHost);
+    for (int m = 0; m < 2; ++m)
+      for (int i = 0; i < 4; ++i)
+        if (dbg[m * 32 + i * 4 + 3] > 0)
+          fprintf(stderr, "k_wgemm2<%d> stamp wg%d wave%d, cycles per tile: all %.0f, waits at the chunk barriers %.0f, epilogue %.0f (%.0f tiles)\n", m ? 2 : 0,
+                  i >> 1 ? 200 : 3, i & 1 ? 5 : 0, dbg[m * 32 + i * 4], dbg[m * 32 + i * 4 + 1], dbg[m * 32 + i * 4 + 2], dbg[m * 32 + i * 4 + 3]);
+  }
+#endif
 #ifdef SF_EXPERIMENT_STAMP
   if (!h->wide) {
     float dbg[64];

@@ -344,6 +344,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
       }
     }
   };
+  // the same, one LDS-DMA instruction at a time (i-th of this wave's G): issued BETWEEN MFMAs an instruction costs its wave ~60
+  // issue cycles, four in a burst behind a barrier 150-200 each (k_wdw's measurement)
+  auto stage_piece = [&](int tsb, int c, int i) __attribute__((always_inline)) {
+    char* base = smem + (c % NB) * SLOT;
+    const long pbg = (long)tsb * NPB;
+    if (i < GA) {
+      const int pc = wave + NWV * i, ot = pc >> 1, s2 = pc & 1;
+      glds16s(Ablk + ((size_t)((c >> 1) * OT + ot) * 4 + 2 * (c & 1) + s2) * 64, (uint32_t)lane * 16u, base + pc * 1024);
+    } else {
+      const int pc = wave + NWV * (i - GA);
+      if constexpr (IN8) {
+        glds16s(a.Bin + ((pbg + pc) * (a.ks_in / 2) + c) * 64, (uint32_t)lane * 16u, base + (16 + pc) * 1024);
+      } else {
+        const int p = pc >> 1, s2 = pc & 1;
+        glds16s(a.Bin + ((pbg + p) * a.ks_in + 2 * c + s2) * 64, (uint32_t)lane * 16u, base + (16 + pc) * 1024);
+      }
+    }
+  };
   f32x16 init[TW];
 #pragma unroll
   for (int t = 0; t < TW; ++t) {
@@ -363,6 +381,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
 #endif
   for (int c = 0; c < PD && c < n2; ++c) stage(sb, c);
   bool first = true;
+#ifdef SF_WEXP_STAMP   // timing-only build: where a wave's tile goes (waits at the chunk barriers / products / epilogue), in cycles
+  unsigned long long st_wait = 0, st_epi = 0, st_tiles = 0;
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
   while (true) {
     const long pb0 = (long)sb * NPB + pw;
     f32x16 acc[TW][PBW];
@@ -371,9 +393,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
 #pragma unroll
       for (int p = 0; p < PBW; ++p) acc[t][p] = init[t];
     u32x4 pv[TW][PBW][P8 ? 1 : 2];                         // MODE 2: phases for the cos factor, requested early
-    for (int c = 0; c < n2; ++c) {
+    // The chunk loop is SOFTWARE-PIPELINED over its operand fragments (round 3): the six fragments of a k-step are read from LDS
+    // while the eight MFMAs of the k-step before run, and the barrier that admits chunk c + 1 sits in the MIDDLE of chunk c
+    // (its fragments are requested under chunk c's second k-step).  hipcc's own order read two fragments, waited for them and
+    // issued their MFMAs, sixteen chunk barriers per tile in between: stamps showed 27 k cycles of main loop per tile and wave
+    // for 8 k cycles of MFMA per SIMD.
+    auto admit = [&](int c, bool burst) __attribute__((always_inline)) {   // chunk c landed and its slot's predecessor is free; burst: request chunk c + PD here
       // vmcnt is in-order: "chunk c landed" = all but the younger operations done; younger are the DMA of chunks
       // c+1, c+2 and - in the first PD steps of a tile that follows another - that tile's NEP epilogue stores
+#ifdef SF_WEXP_STAMP
+      const unsigned long long st_w0 = __builtin_amdgcn_s_memtime();
+#endif
       // (in flight behind chunk c: min(PD - 1, n2 - 1 - c) chunks of G instructions each)
       if (!pipe) bar_all();
 #ifndef SF_WEXP_LAXWAIT
@@ -386,7 +416,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
       else if (first || c >= PD) bar_dma<(PD - 1) * G>();
       else bar_dma<(PD - 1) * G + NEP>();
 #endif
-      if (c + PD < n2) stage(sb, c + PD);
+#ifdef SF_WEXP_STAMP
+      st_wait += __builtin_amdgcn_s_memtime() - st_w0;
+#endif
+      if (burst && c + PD < n2) stage(sb, c + PD);
       asm volatile("" ::: "memory");
       if (MODE == 2 && c == n2 - 1) {
 #pragma unroll
@@ -401,29 +434,75 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
                 pv[t][p][qq] = a.Pprev[((pb0 + p) * a.ks_out + 16 * ob + 2 * (t0 + t) + qq) * 64 + lane];
             }
       }
+    };
+    struct Frags { u32x4 fa[TW]; u32x4 b[PBW]; };
+    u32x4 braw[PBW];                                       // IN8: the byte pieces of the current chunk (both k-steps)
+    auto frag_load = [&](int c, int s2, Frags& f) __attribute__((always_inline)) {
       const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
       const u32x4* sB = sA + 16 * 64;
-      u32x4 braw[PBW];
       if constexpr (IN8) {
+        if (s2 == 0) {
 #pragma unroll
-        for (int p = 0; p < PBW; ++p) braw[p] = sB[(pw + p) * 64];
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        u32x4 b[PBW];
-#pragma unroll
-        for (int p = 0; p < PBW; ++p) {
-          if constexpr (IN8) b[p] = s2 == 0 ? fp8x8_to_f16(braw[p].x, braw[p].y) : fp8x8_to_f16(braw[p].z, braw[p].w);
-          else b[p] = sB[((pw + p) * 2 + s2) * 64];
+          for (int p = 0; p < PBW; ++p) braw[p] = sB[(pw + p) * 64];
         }
 #pragma unroll
-        for (int t = 0; t < TW; ++t) {
-          const u32x4 fa = sA[((t0 + t) * 2 + s2) * 64];
+        for (int p = 0; p < PBW; ++p) f.b[p] = s2 == 0 ? fp8x8_to_f16(braw[p].x, braw[p].y) : fp8x8_to_f16(braw[p].z, braw[p].w);
+      } else {
 #pragma unroll
-          for (int p = 0; p < PBW; ++p) acc[t][p] = OP::mfma(fa, b[p], acc[t][p]);
+        for (int p = 0; p < PBW; ++p) f.b[p] = sB[((pw + p) * 2 + s2) * 64];
+      }
+#pragma unroll
+      for (int t = 0; t < TW; ++t) f.fa[t] = sA[((t0 + t) * 2 + s2) * 64];
+    };
+    // cstage >= 0: the G LDS-DMA instructions of chunk cstage are issued one after every second MFMA of this k-step
+    auto mma_step = [&](const Frags& f, int cstage) __attribute__((always_inline)) {
+      constexpr int PPS = (G + TW - 1) / TW;               // DMA instructions behind each row tile's MFMAs
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+#pragma unroll
+        for (int p = 0; p < PBW; ++p) acc[t][p] = OP::mfma(f.fa[t], f.b[p], acc[t][p]);
+        if (cstage >= 0) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = t * PPS; i < (t + 1) * PPS && i < G; ++i) stage_piece(sb, cstage, i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    // (the 16-bit-phase data gradient holds 64 registers of phases in its last chunks: no room for a second fragment set there)
+    constexpr bool DB = !(MODE == 2 && !P8);
+    Frags f0, f1;
+    admit(0, true);
+    frag_load(0, 0, f0);
+    for (int c = 0; c < n2; ++c) {
+      const bool nxt = c + 1 < n2;
+      if constexpr (DB) {
+        frag_load(c, 1, f1);                               // under the MFMAs of k-step (c, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(f0, -1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt) {
+          admit(c + 1, false);
+          frag_load(c + 1, 0, f0);                         // under the MFMAs of k-step (c, 1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(f1, nxt && c + 1 + PD < n2 ? c + 1 + PD : -1);   // chunk c + 1 + PD goes into the slot chunk c has just left
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        mma_step(f0, -1);
+        frag_load(c, 1, f0);
+        mma_step(f0, -1);
+        if (nxt) {
+          admit(c + 1, true);
+          frag_load(c + 1, 0, f0);
         }
       }
     }
+    (void)f1;
+#ifdef SF_WEXP_STAMP
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[TW - 1][PBW - 1][15]));
+    const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+#endif
     const int sbn = sb + sb_step;
     const bool more = sbn < a.n_super;
     if (pipe && more) {
@@ -512,6 +591,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
           if constexpr (OUT8) WST(a.Out[((pb0 + p) * a.kp_out + 8 * ob + (t0 + t)) * 64 + lane], (u32x4{o8[0], o8[1], o8[2], o8[3]}));
         }
     }
+#ifdef SF_WEXP_STAMP
+    st_epi += __builtin_amdgcn_s_memtime() - st_e0;
+    st_tiles += 1;
+#endif
     if (!more) break;
     if (!pipe) {
       bar_lds();
@@ -520,6 +603,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
     sb = sbn;
     first = false;
   }
+#ifdef SF_WEXP_STAMP
+  if (a.dump && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 200) && st_tiles) {
+    float* o = reinterpret_cast<float*>(a.dump) + (MODE == 0 ? 0 : 32) + ((blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 4;
+    const float nt = (float)st_tiles;
+    o[0] = (float)(__builtin_amdgcn_s_memtime() - st_begin) / nt; o[1] = (float)st_wait / nt; o[2] = (float)st_epi / nt; o[3] = nt;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
