@@ -624,7 +624,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
 //   an activation store every 8 values, a phase-byte store every 16: 12 stores spread over the tile's k-steps.
 //   Every step is the full step (k_bwd8h's rule): the first tile drains zeros into a.dump, requests beyond the last tile re-read
 //   its chunks, the last tile is drained once more at the end - so the store pattern is periodic and every vmcnt is a constant.
-// RESULT: parity-green and exactly as fast as the tile loop (forward 20.3 against 20.0 ms per step at 512x8): it is not the burst.
+// RESULT: bit-identical to the tile loop and no faster (forward 20.3 against 20.0 ms per step at 512x8; with the fragments of both
+// loops double-buffered 20.5 against 18.6): it is not the burst, and the smaller tile pays more than the hidden epilogue returns.
 // KSI = k-steps of the layer (32 at width 512, 64 at 1024).  fp16 operands, phase bytes (scratch formats 12 / 8).
 // ---------------------------------------------------------------------------------------------------------
 template <int V> struct IntC { static constexpr int value = V; };
@@ -664,8 +665,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int t = 0; t < TW; ++t) { accA[t] = f32x16{}; accB[t] = f32x16{}; }
   static_assert(N2 % NB == 0 && PD < N2, "ring slots are compile-time inside a tile");
-  for (int c = 0; c < PD; ++c) stage(0, c, c);
-  // the counted waits below assume the store pattern of a tile BEFORE the first one: with the first three chunks (and the bias
+  for (int c = 0; c <= PD; ++c) stage(0, c, c);
+  // the counted waits below assume the store pattern of a tile BEFORE the first one: with the first four chunks (and the bias
   // table) landed here they hold from step 0 (the later chunks of tile 0 are requested behind real - dumped - stores)
   bar_all();
   u32x4* const dumpw = a.dump + wave * 64 + lane;
@@ -713,16 +714,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       *dst = u32x4{e_p0, e_p1, e_p2, e_p3};
     }
   };
-  // stores issued in chunk-step c of a tile (c taken modulo the tile: the pattern is the same in every tile)
-  auto stores_in = [](int c) constexpr -> int {
-    const int cc = ((c % N2) + N2) % N2;
+  // stores issued in half-step hs = 2 c + s2 of a tile (taken modulo the tile: the pattern is the same in every tile)
+  auto stores_half = [](int hs) constexpr -> int {
+    const int hh = ((hs % (2 * N2)) + 2 * N2) % (2 * N2);
     int n = 0;
-    for (int s2 = 0; s2 < 2; ++s2)
-      for (int u = 0; u < VPK; ++u) {
-        const int e = (((2 * cc + s2) * VPK + u) & 15);
-        n += ((e & 7) == 7) + (e == 15);
-      }
+    for (int u = 0; u < VPK; ++u) {
+      const int e = ((hh * VPK + u) & 15);
+      n += ((e & 7) == 7) + (e == 15);
+    }
     return n;
+  };
+  // The operand fragments are double-buffered across half-steps (as in k_wgemm2): f0 holds k-step (c, 0), f1 k-step (c, 1); the
+  // barrier that admits chunk c + 1 sits between the two half-steps of chunk c, where chunk c + 1 + PD is requested too.
+  struct Frags { u32x4 fa[TW]; u32x4 b; };
+  Frags f0, f1;
+  auto frag_load = [&](int c, int s2, Frags& f) __attribute__((always_inline)) {
+    const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
+    f.b = sA[(16 + pbw * 2 + s2) * 64];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) f.fa[t] = sA[((t0 + t) * 2 + s2) * 64];
   };
   // one tile: `cur` accumulates (its bias first), `prv` - the tile before - is drained into pixel block pbp (or the dump).
   // The chunk loop is unrolled sixteen chunks at a time through a compile-time part index (a 32-chunk body is not unrolled
@@ -731,31 +741,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int PART = decltype(part_tag)::value;
 #pragma unroll
     for (int ci = 0; ci < 16; ++ci) {
-      constexpr int dummy = 0; (void)dummy;
       const int c = 16 * PART + ci;
-      // chunk c landed: younger than its DMA are the DMA of the next PD - 1 chunks and the stores of the last PD steps
-      const int nst = stores_in(c - 3) + stores_in(c - 2) + stores_in(c - 1);
-      switch (nst) {                                     // (a constant per c after unrolling)
-        case 0: bar_dma<(PD - 1) * G + 0>(); break;
-        case 1: bar_dma<(PD - 1) * G + 1>(); break;
-        case 2: bar_dma<(PD - 1) * G + 2>(); break;
-        case 3: bar_dma<(PD - 1) * G + 3>(); break;
-        case 4: bar_dma<(PD - 1) * G + 4>(); break;
-        case 5: bar_dma<(PD - 1) * G + 5>(); break;
-        default: bar_dma<(PD - 1) * G + 6>(); break;
+      frag_load(c, 1, f1);                               // under the MFMAs of half-step (c, 0)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TW; ++t) cur[t] = OP::mfma(f0.fa[t], f0.b, cur[t]);
+#pragma unroll
+      for (int u = 0; u < VPK; ++u) epi_value(prv, (2 * c) * VPK + u, pbp, to_dump);
+      __builtin_amdgcn_sched_barrier(0);
+      {   // admit chunk c + 1 (of this tile or the first of the next): younger than its DMA are the DMA of the PD - 1 chunks
+          // requested since and the stores of the 2 PD half-steps (c - PD, 1) .. (c, 0)
+        int nst = 0;
+        for (int hs = 2 * (c + 1) - 2 * PD - 1; hs <= 2 * c; ++hs) nst += stores_half(hs);
+        switch (nst) {                                   // (a constant per c after unrolling)
+          case 0: bar_dma<(PD - 1) * G + 0>(); break;
+          case 1: bar_dma<(PD - 1) * G + 1>(); break;
+          case 2: bar_dma<(PD - 1) * G + 2>(); break;
+          case 3: bar_dma<(PD - 1) * G + 3>(); break;
+          case 4: bar_dma<(PD - 1) * G + 4>(); break;
+          case 5: bar_dma<(PD - 1) * G + 5>(); break;
+          default: bar_dma<(PD - 1) * G + 6>(); break;
+        }
+        const int cn = c + 1 + PD;                       // chunk requested here: into the slot chunk c has just left
+        if (cn < N2) stage(ti, cn, cn % NB); else stage(ti + 1, cn - N2, cn % NB);
+        asm volatile("" ::: "memory");
+        frag_load(c + 1, 0, f0);                         // under the MFMAs of half-step (c, 1); (chunk N2 = chunk 0 of the next tile: same slot)
       }
-      if (c + PD < N2) stage(ti, c + PD, (c + PD) % NB); else stage(ti + 1, c + PD - N2, (c + PD) % NB);
-      asm volatile("" ::: "memory");
-      const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
-      const u32x4* sB = sA + 16 * 64;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const u32x4 b = sB[(pbw * 2 + s2) * 64];
+      for (int t = 0; t < TW; ++t) cur[t] = OP::mfma(f1.fa[t], f1.b, cur[t]);
 #pragma unroll
-        for (int t = 0; t < TW; ++t) cur[t] = OP::mfma(sA[((t0 + t) * 2 + s2) * 64], b, cur[t]);
-#pragma unroll
-        for (int u = 0; u < VPK; ++u) epi_value(prv, (2 * c + s2) * VPK + u, pbp, to_dump);
-      }
+      for (int u = 0; u < VPK; ++u) epi_value(prv, (2 * c + 1) * VPK + u, pbp, to_dump);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto tile = [&](f32x16 (&cur)[TW], const f32x16 (&prv)[TW], int ti, long pbp, bool to_dump) __attribute__((always_inline)) {
@@ -769,6 +786,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tile_part(IntC<0>{}, cur, prv, ti, pbp, to_dump);
     if constexpr (N2 > 16) tile_part(IntC<1>{}, cur, prv, ti, pbp, to_dump);
   };
+  frag_load(0, 0, f0);
   // tiles alternate between the two accumulator sets
   long pb_prev = 0;
   int ti = 0;
