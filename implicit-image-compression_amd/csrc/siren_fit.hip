@@ -1200,8 +1200,8 @@ int sf_destroy(sf_handle* h) try {
     for (int m = 0; m < 2; ++m)
       for (int i = 0; i < 4; ++i)
         if (dbg[m * 32 + i * 4 + 3] > 0)
-          fprintf(stderr, "k_wgemm2<%d> stamp wg%d wave%d, cycles per tile: all %.0f, waits at the chunk barriers %.0f, epilogue %.0f (%.0f tiles)\n", m ? 2 : 0,
-                  i >> 1 ? 200 : 3, i & 1 ? 5 : 0, dbg[m * 32 + i * 4], dbg[m * 32 + i * 4 + 1], dbg[m * 32 + i * 4 + 2], dbg[m * 32 + i * 4 + 3]);
+          fprintf(stderr, "k_wgemm2<%d> stamp wg%d wave%d, cycles per tile: all %.0f, waits at the chunk barriers %.0f, epilogue %.0f (%.0f tiles), core clock %.0f MHz\n", m ? 2 : 0,
+                  i >> 1 ? 200 : 3, i & 1 ? 5 : 0, dbg[m * 32 + i * 4], dbg[m * 32 + i * 4 + 1], dbg[m * 32 + i * 4 + 2], dbg[m * 32 + i * 4 + 3], dbg[m * 32 + 16 + i]);
   }
 #endif
 #ifdef SF_EXPERIMENT_STAMP

@@ -326,6 +326,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
   const bool pipe = n2 >= 4;                             // cross-tile prefetch (the K = 32 last-layer product: plain waits)
   static_assert(PD == 2 || PD == 3, "the wait plan below");
   auto stage = [&](int tsb, int c) {
+#ifdef SF_WEXP_NODMA   // timing-only: nothing is staged (the products run on whatever the LDS holds)
+    return;
+#endif
     char* base = smem + (c % NB) * SLOT;
     const long pbg = (long)tsb * NPB;
 #pragma unroll
@@ -347,6 +350,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
   // the same, one LDS-DMA instruction at a time (i-th of this wave's G): issued BETWEEN MFMAs an instruction costs its wave ~60
   // issue cycles, four in a burst behind a barrier 150-200 each (k_wdw's measurement)
   auto stage_piece = [&](int tsb, int c, int i) __attribute__((always_inline)) {
+#ifdef SF_WEXP_NODMA
+    return;
+#endif
     char* base = smem + (c % NB) * SLOT;
     const long pbg = (long)tsb * NPB;
     if (i < GA) {
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
   bool first = true;
 #ifdef SF_WEXP_STAMP   // timing-only build: where a wave's tile goes (waits at the chunk barriers / products / epilogue), in cycles
   unsigned long long st_wait = 0, st_epi = 0, st_tiles = 0;
-  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime(), st_rt0 = __builtin_amdgcn_s_memrealtime();   // core cycles, 100 MHz ticks
 #endif
   while (true) {
     const long pb0 = (long)sb * NPB + pw;
@@ -438,6 +444,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
     struct Frags { u32x4 fa[TW]; u32x4 b[PBW]; };
     u32x4 braw[PBW];                                       // IN8: the byte pieces of the current chunk (both k-steps)
     auto frag_load = [&](int c, int s2, Frags& f) __attribute__((always_inline)) {
+#ifdef SF_WEXP_NOLDS   // timing-only: the fragments are never read from LDS (opaque register values)
+#pragma unroll
+      for (int t = 0; t < TW; ++t) asm volatile("" : "+v"(f.fa[t]));
+#pragma unroll
+      for (int p = 0; p < PBW; ++p) asm volatile("" : "+v"(f.b[p]));
+      return;
+#endif
       const u32x4* sA = reinterpret_cast<const u32x4*>(smem + (c % NB) * SLOT) + lane;
       const u32x4* sB = sA + 16 * 64;
       if constexpr (IN8) {
@@ -471,28 +484,34 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
     };
     // (the 16-bit-phase data gradient holds 64 registers of phases in its last chunks: no room for a second fragment set there)
     constexpr bool DB = !(MODE == 2 && !P8);
-    Frags f0, f1;
+    Frags f0 = {}, f1 = {};
     admit(0, true);
     frag_load(0, 0, f0);
-    for (int c = 0; c < n2; ++c) {
-      const bool nxt = c + 1 < n2;
-      if constexpr (DB) {
+    if constexpr (DB) {
+      // The LAST chunk is peeled off: with an `if (c + 1 < n2)` around the admit and the next fragment reads, hipcc's wait insertion
+      // merged the two paths into the second k-step and put lgkmcnt(3..0) before its MFMAs - in the common path that waits for the
+      // six fragment reads issued just before, i.e. the LDS latency of the NEXT k-step was exposed in every chunk.
+      for (int c = 0; c + 1 < n2; ++c) {
         frag_load(c, 1, f1);                               // under the MFMAs of k-step (c, 0)
         __builtin_amdgcn_sched_barrier(0);
         mma_step(f0, -1);
         __builtin_amdgcn_sched_barrier(0);
-        if (nxt) {
-          admit(c + 1, false);
-          frag_load(c + 1, 0, f0);                         // under the MFMAs of k-step (c, 1)
-        }
+        admit(c + 1, false);
+        frag_load(c + 1, 0, f0);                           // under the MFMAs of k-step (c, 1)
         __builtin_amdgcn_sched_barrier(0);
-        mma_step(f1, nxt && c + 1 + PD < n2 ? c + 1 + PD : -1);   // chunk c + 1 + PD goes into the slot chunk c has just left
+        mma_step(f1, c + 1 + PD < n2 ? c + 1 + PD : -1);   // chunk c + 1 + PD goes into the slot chunk c has just left
         __builtin_amdgcn_sched_barrier(0);
-      } else {
+      }
+      frag_load(n2 - 1, 1, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(f0, -1);
+      mma_step(f1, -1);
+    } else {
+      for (int c = 0; c < n2; ++c) {
         mma_step(f0, -1);
         frag_load(c, 1, f0);
         mma_step(f0, -1);
-        if (nxt) {
+        if (c + 1 < n2) {
           admit(c + 1, true);
           frag_load(c + 1, 0, f0);
         }
@@ -608,6 +627,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void k_wgemm2(WGemmArgs
     float* o = reinterpret_cast<float*>(a.dump) + (MODE == 0 ? 0 : 32) + ((blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 4;
     const float nt = (float)st_tiles;
     o[0] = (float)(__builtin_amdgcn_s_memtime() - st_begin) / nt; o[1] = (float)st_wait / nt; o[2] = (float)st_epi / nt; o[3] = nt;
+    reinterpret_cast<float*>(a.dump)[(MODE == 0 ? 16 : 48) + (blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1)] =
+        (float)(__builtin_amdgcn_s_memtime() - st_begin) / (float)(__builtin_amdgcn_s_memrealtime() - st_rt0) * 100.0f;   // core MHz over the launch
   }
 #endif
 }
