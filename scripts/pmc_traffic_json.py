@@ -26,6 +26,8 @@ NAMES = [("k_fwd<256", "k_fwd"), ("k_fwd_pipe<", "k_fwd"), ("k_bwd<32, 256", "k_
 
 
 def main():
+    if len(sys.argv) < 3 or sys.argv[1].startswith("-"):
+        sys.exit("usage: pmc_traffic_json.py OUT.json PMC_DIR [PMC_DIR ...]")
     out, dirs = sys.argv[1], sys.argv[2:]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     full = {}
