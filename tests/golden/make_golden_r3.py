@@ -111,6 +111,11 @@ def main():
         threads = tuple(int(t) for t in os.environ.get("NS_THREADS", "8,2").split(","))
         img, grid = nonsmooth_image(S, S), data.get_grid(S, S)
         two_runs(th, siren, grid, img, 256, 8, 200, 40, f"plateau_ns_256x8_{S}", threads=threads)
+    if "wide" in what:
+        # the wide path against the real reference end to end (hidden 512: csrc/siren_wide.hip), one 8-thread run
+        S, steps = int(os.environ.get("NS_SIZE", "512")), int(os.environ.get("NS_STEPS", "200"))
+        img, grid = nonsmooth_image(S, S), data.get_grid(S, S)
+        two_runs(th, siren, grid, img, 512, 4, steps, 40, f"plateau_ns_512x4_{S}", threads=(8,))
 
 
 if __name__ == "__main__":
