@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--scratch", type=int, default=0, choices=[0, 8, 12, 16],
-                    help="sf_config.scratch_format: 0 = auto (hidden <= 256, fp16: 8 = phase bytes + fp8 deltas from 2^20 pixels, 12 = phase bytes + 16-bit deltas below), 16 = round-1 format")
+                    help="sf_config.scratch_format: 0 = auto (fp16, hidden <= 512: 8 = phase bytes + fp8 deltas from 2^20 pixels; below that 12 = phase bytes + 16-bit deltas at hidden <= 256), 16 = round-1 format")
     ap.add_argument("--no-formats", action="store_true", help="skip the by_scratch_format leg (5 warm-up + 10 timed steps per format after the headline region)")
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")

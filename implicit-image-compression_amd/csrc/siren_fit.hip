@@ -1102,8 +1102,10 @@ int sf_create(const sf_config* cfg, sf_handle** out) try {
     int fmt = cfg->scratch_format;
     h->fmt_auto = fmt == 0;
     const bool mega = (double)cfg->height * (double)cfg->width >= 1048576.0;
-    // (wider than 256: the layer-at-a-time kernels have phase bytes only, and take them where bandwidth matters - from 2^20 pixels)
-    if (fmt == 0) fmt = cfg->compute_dtype != SF_F16 ? 16 : h->wide ? (mega ? 12 : 16) : (mega ? 8 : 12);
+    // (wider than 256: the layer-at-a-time kernels take the byte formats where bandwidth matters - from 2^20 pixels; fp8 deltas up to
+    // width 512, where a reference-minted fixture at 2^20 pixels pins them (tests/golden/plateau_ns_512x4_1024.npz: -0.0002 dB);
+    // phase bytes only above)
+    if (fmt == 0) fmt = cfg->compute_dtype != SF_F16 ? 16 : h->wide ? (mega ? (cfg->hidden <= 512 ? 8 : 12) : 16) : (mega ? 8 : 12);
     h->cfg.scratch_format = fmt;
     h->s8 = fmt == 8 || fmt == 12;
     h->d8 = fmt == 8;

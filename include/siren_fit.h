@@ -77,8 +77,8 @@ typedef struct sf_config {
                              *  8 = phase bytes + fp8 e4m3 deltas under one power-of-two scale per pixel chunk (from the
                              *      chunk's residual) times one per layer (from the layer's weight norm);
                              *  0 = auto, SF_F16 only (8 and 12 need fp16 operands; else 16): hidden <= 256: 8 for images of
-                             *      >= 2^20 pixels, 12 below; hidden > 256: 12 from 2^20 pixels, 16 below (8 is accepted
-                             *      there when asked for).  An auto handle moves to 16 when sf_set_masks sets a mask
+                             *      >= 2^20 pixels, 12 below; hidden > 256: from 2^20 pixels 8 up to hidden 512 and 12 above
+                             *      (8 is accepted there when asked for), 16 below.  An auto handle moves to 16 when sf_set_masks sets a mask
                              *      (sparse networks: DESIGN.md section 2)                                             */
 } sf_config;
 

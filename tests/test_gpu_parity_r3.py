@@ -346,8 +346,8 @@ def test_wide_phase_bytes_gradients(H, W, hidden, depth, chunk):
 
 def test_wide_phase_bytes_psnr_parity_and_auto_rule():
     """(i) test_wide_psnr_parity_after_equal_steps with format 12: SIREN 512x4 on 96x96, 60 Adam steps, within 0.05 dB of the
-    fp32 oracle (measured 0.0002 dB).  (ii) the auto rule: a wide fp16 handle takes phase bytes from 2^20 pixels, format 16
-    below; a mask moves an auto handle back to 16 (one rule with the width-256 path)."""
+    fp32 oracle (measured 0.0002 dB).  (ii) the auto rule: a wide fp16 handle takes the byte formats from 2^20 pixels (width 512: phase bytes + fp8
+    deltas, wider: phase bytes), format 16 below; a mask moves an auto handle back to 16 (one rule with the width-256 path)."""
     H = W = 96
     hidden, depth, steps = 512, 4, 60
     img, grid = so.synthetic_image(H, W, seed=8), so.get_grid(H, W)
@@ -367,11 +367,14 @@ def test_wide_phase_bytes_psnr_parity_and_auto_rule():
     assert small.scratch_format == 16
     small.close()
     big = SirenEngine(1024, 1024, 512, 3)
-    assert big.scratch_format == 12
+    assert big.scratch_format == 8                              # width 512: pinned by plateau_ns_512x4_1024.npz
+    wider = SirenEngine(1024, 1024, 1024, 3)
+    assert wider.scratch_format == 12                           # no reference fixture at width 1024: phase bytes only
+    wider.close()
     big.set_masks(torch.ones(2 * 512 + 512 + 512 * 512 + 512 + 512 * 3 + 3, device="cuda"))
     assert big.scratch_format == 16
     big.close()
-    e8 = SirenEngine(64, 64, 512, 3, scratch_format=8)          # fp8 deltas on the wide path: explicit only
+    e8 = SirenEngine(64, 64, 1024, 3, scratch_format=8)         # fp8 deltas at width 1024: explicit only
     assert e8.scratch_format == 8
     e8.close()
 
@@ -453,7 +456,8 @@ def test_wide_path_non_smooth_plateau_against_the_reference(golden, size, fmt):
     image, 200 steps of the reference's train_epoch with StepLR(40, 0.5) (tests/golden/make_golden_r3.py wide; one 8-thread run).
     Every scratch format of the wide path (16-bit phases / phase bytes / phase bytes + fp8 deltas) has to land within
     BASELINE.json's 0.05 dB of the reference's end PSNR.  Measured at 512 x 512 (reference 20.8192 dB): -0.0001 / -0.0002 / -0.0009 dB
-    for formats 16 / 12 / 8."""
+    for formats 16 / 12 / 8; at 1024 x 1024 (20.7989 dB): -0.0000 / -0.0001 / -0.0002 dB - the fixture the width-512 auto rule
+    (format 8 from 2^20 pixels) rests on."""
     d = golden(f"plateau_ns_512x4_{size}")
     assert int(d["hidden"]) == 512 and int(d["depth"]) == 4
     lr_step = int(d["lr_step"])
