@@ -3,12 +3,14 @@
 for the absent non-arithmetic imports, models/siren.py loaded by path; only DATA is written, the images are regenerated
 from oracle.siren_oracle formulas on the test side and pinned by a sha256).
 
-    python tests/golden/make_golden_r3.py [nonsmooth] [long] [config1] [horizon] [kmeans] [truncate512]
+    python tests/golden/make_golden_r3.py [nonsmooth] [long] [config1] [horizon] [kmeans] [truncate512] [wide]
 
   plateau_ns_256x8_{S}.npz  the metric model (SIREN 256x8) on the S x S NON-SMOOTH image (oracle.nonsmooth_image: step edges,
                             regions clamped at 0 and 1, a one-pixel checkerboard, 0.1 % outlier pixels): 200 full-batch steps
                             of the reference's train_epoch, Adam lr 3e-4, StepLR(40, 0.5).  8 and 2 torch threads: the
                             reference's own summation-order spread is stored (NS_SIZE / NS_THREADS select other sizes).
+  plateau_ns_512x4_{512,1024}.npz   `wide` with NS_SIZE=512 / 1024: SIREN 512x4 (the wide kernels) on the non-smooth image, 200 steps,
+                            StepLR(40, 0.5), one 8-thread run each (8 and 33 minutes on this container's 8 cores).
   long_64x4_256.npz         the reference's REAL schedule - get_optimizer_lr_scheduler's StepLR(2000, 0.5)
   long_128x6_128.npz        (train_helper.py:80-84) - over 4000 steps (64x4 on the 256 x 256, 128x6 on the 128 x 128 non-smooth
                             image): loss curve, end PSNR, mean loss of the last 200 steps; 8 and 2 threads.
